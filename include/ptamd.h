@@ -1,0 +1,202 @@
+/* ptamd — C ABI of the MI355X render hot path.
+ *
+ * The reference (Sh-Anand/pathtracer) has no FFI; its seam is internal C++:
+ * RaytracedRenderer owns a PathTracer and a BVHAccel and its worker threads call
+ * pt->raytrace_pixel(x, y) per pixel (src/pathtracer/raytraced_renderer.cpp:
+ * 268-329, 585-610, 644-678). This header is the boundary a maintainer would
+ * bind instead: plain C structs, pointers and sizes; every function returns an
+ * int status (0 = ok) and ptamd_last_error() explains a failure. Nothing here
+ * ever calls exit().
+ *
+ * Conventions shared by every entry point
+ *  - all geometry is FP64, in the reference's BVH primitive order;
+ *  - pixel (x, y) has index x + y*w with y = 0 the BOTTOM row, as in the
+ *    reference's sampleBuffer (src/pathtracer/pathtracer.cpp:270-271);
+ *  - "hdr" is 3 doubles per pixel (mean radiance), "count" one int32 per pixel
+ *    (samples actually taken, src/pathtracer/pathtracer.cpp:271).
+ */
+#ifndef PTAMD_H
+#define PTAMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PTAMD_OK 0
+#define PTAMD_ERR_ARG 1     /* bad argument / shape mismatch            */
+#define PTAMD_ERR_IO 2      /* file missing or unparsable               */
+#define PTAMD_ERR_SCENE 3   /* scene violates a loader/builder invariant */
+#define PTAMD_ERR_DEVICE 4  /* HIP call failed or no GPU                */
+#define PTAMD_ERR_STATE 5   /* call order wrong (e.g. render before upload) */
+
+/* primitive / material / light kinds used in ptamd_scene_desc */
+#define PTAMD_PRIM_TRIANGLE 0
+#define PTAMD_PRIM_SPHERE 1
+#define PTAMD_MAT_DIFFUSE 0
+#define PTAMD_MAT_EMISSION 1
+#define PTAMD_MAT_MIRROR 2
+#define PTAMD_MAT_MICROFACET 3
+#define PTAMD_MAT_REFRACTION 4
+#define PTAMD_MAT_GLASS 5
+#define PTAMD_LIGHT_DIRECTIONAL 0
+#define PTAMD_LIGHT_INF_HEMISPHERE 1
+#define PTAMD_LIGHT_POINT 2
+#define PTAMD_LIGHT_SPOT 3
+#define PTAMD_LIGHT_AREA 4
+
+/* Flattened static scene. Replaces the pointer graph the reference builds in
+ * RaytracedRenderer::set_scene / build_accel (raytraced_renderer.cpp:106-128,
+ * 351-375): Scene{objects, lights}, Triangle/Sphere objects, BVHAccel::nodes.
+ * The caller keeps ownership of every array. */
+typedef struct ptamd_scene_desc {
+  int32_t n_prims, n_nodes, n_materials, n_lights, root, jitter_n;
+  const int32_t *prim_type;     /* [n_prims]                                          */
+  const double *prim_pos;       /* [n_prims*9] tri: p1,p2,p3; sphere: c.xyz, r, r*r    */
+  const double *prim_nrm;       /* [n_prims*9] tri: n1,n2,n3 (not renormalised)        */
+  const int32_t *prim_material; /* [n_prims] index into mat_*                          */
+  const double *node_bbox;      /* [n_nodes*6] min.xyz, max.xyz                        */
+  const int32_t *node_left;     /* [n_nodes] -1 for leaves                             */
+  const int32_t *node_right;    /* [n_nodes]                                           */
+  const int32_t *node_start;    /* [n_nodes] leaf: first primitive                     */
+  const int32_t *node_count;    /* [n_nodes] leaf: primitive count (>0), interior: 0   */
+  const int32_t *mat_kind;      /* [n_materials]                                       */
+  const double *mat_param;      /* [n_materials*3] reflectance | radiance | ...        */
+  const int32_t *light_kind;    /* [n_lights]                                          */
+  const double *light_param;    /* [n_lights*16] radiance, position, direction,
+                                   dim_x, dim_y (3 each), area                         */
+  const double *jitter_table;   /* [jitter_n*jitter_n*2] pre-jittered sub-pixel table
+                                   (src/pathtracer/sampler.h:78-89)                    */
+} ptamd_scene_desc;
+
+/* Replaces the Camera fields generate_ray reads (src/pathtracer/camera.cpp:190-203). */
+typedef struct ptamd_camera {
+  double pos[3];
+  double c2w[9]; /* column-major: c2w[3*col + row] */
+  double hFov, vFov, nClip, fClip; /* degrees */
+} ptamd_camera;
+
+/* Replaces the PathTracer public configuration fields
+ * (src/pathtracer/pathtracer.h:73-83) plus the frame/cell rectangle of
+ * RaytracedRenderer (raytraced_renderer.cpp:159-177, 303-321). */
+typedef struct ptamd_render_params {
+  int32_t w, h;               /* frame size                                         */
+  int32_t x0, y0, x1, y1;     /* half-open pixel rectangle to render                */
+  int32_t ns_aa;              /* -s samples per pixel                               */
+  int32_t max_ray_depth;      /* -m                                                 */
+  int32_t accumulate_bounces; /* -o                                                 */
+  int32_t ns_area_light;      /* -l                                                 */
+  int32_t samples_per_batch;  /* -a (first word)                                    */
+  int32_t hemisphere;         /* -H direct lighting by uniform hemisphere sampling  */
+  double max_tolerance;       /* -a (second word)                                   */
+  uint64_t seed;              /* key of the counter-based per-pixel RNG             */
+} ptamd_render_params;
+
+typedef struct ptamd_stats {
+  double seconds;          /* wall time of the last render (device work only)     */
+  uint64_t samples;        /* sum of per-pixel sample counts                      */
+  uint64_t rays;           /* camera + extension + shadow rays traced             */
+  uint64_t shadow_rays;
+  uint64_t path_vertices;  /* shaded hits                                         */
+  uint64_t nodes_visited;  /* BVH nodes popped (only when counters are enabled)   */
+  uint64_t prim_tests;     /* primitive tests  (only when counters are enabled)   */
+  uint64_t launches[8];    /* kernel launches per kernel class                    */
+  double kernel_ms[8];     /* summed HIP-event time per kernel class (profiling)  */
+} ptamd_stats;
+
+/* kernel classes for ptamd_stats.launches / kernel_ms */
+#define PTAMD_K_GENERATE 0
+#define PTAMD_K_EXTEND 1
+#define PTAMD_K_SHADE 2
+#define PTAMD_K_SHADOW 3
+#define PTAMD_K_RESOLVE 4
+#define PTAMD_K_ACCUMULATE 5
+#define PTAMD_K_FILTER 6
+#define PTAMD_K_OTHER 7
+
+typedef struct ptamd_scene ptamd_scene;     /* host scene (parsed + built) */
+typedef struct ptamd_context ptamd_context; /* one GPU                     */
+
+const char *ptamd_last_error(void);
+
+/* ---- host scene pipeline -------------------------------------------------
+ * ptamd_scene_load replaces Collada::ColladaParser::load
+ * (src/scene/collada/collada.cpp:133-227), Application::load
+ * (src/application/application.cpp:229-305) and
+ * RaytracedRenderer::build_accel (raytraced_renderer.cpp:351-375). */
+int ptamd_scene_load(const char *dae_path, ptamd_scene **out);
+void ptamd_scene_free(ptamd_scene *scene);
+/* Pointers in *out stay valid until ptamd_scene_free. */
+int ptamd_scene_get_desc(const ptamd_scene *scene, ptamd_scene_desc *out);
+/* Camera for a w x h frame; replaces Application::resize -> Camera::set_screen_size
+ * (application.cpp:189-201, camera.cpp:83-89). w = h = 0 keeps 800x600. */
+int ptamd_scene_get_camera(ptamd_scene *scene, int32_t w, int32_t h, ptamd_camera *out);
+/* Replaces Camera::load_settings (camera.cpp:170-185), the -c option. */
+int ptamd_scene_load_camera_file(ptamd_scene *scene, const char *path);
+/* BVH build wall time in seconds (what build_accel prints). */
+double ptamd_scene_build_seconds(const ptamd_scene *scene);
+
+/* ---- device layer ---------------------------------------------------------
+ * Replaces the worker pool: start_raytracing / worker_thread / raytrace_tile
+ * (raytraced_renderer.cpp:268-329, 644-678, 585-610) and everything below
+ * PathTracer::raytrace_pixel (src/pathtracer/pathtracer.cpp:234-272). */
+int ptamd_create(int32_t device_id, ptamd_context **out);
+void ptamd_destroy(ptamd_context *ctx);
+/* Copies the scene to the device (replaces set_scene + build_accel's hand-over). */
+int ptamd_upload_scene(ptamd_context *ctx, const ptamd_scene_desc *desc);
+/* Replaces RaytracedRenderer::set_camera (raytraced_renderer.cpp:136-149). */
+int ptamd_set_camera(ptamd_context *ctx, const ptamd_camera *cam);
+/* Bound on paths in flight per wavefront pass (0 = default). */
+int ptamd_set_max_paths(ptamd_context *ctx, int64_t max_paths);
+/* Enables per-launch HIP-event timing and traversal counters (slower). */
+int ptamd_set_profiling(ptamd_context *ctx, int32_t events, int32_t counters);
+
+/* Whole frame on this GPU: replaces render_to_file's start_raytracing +
+ * wait-for-DONE (raytraced_renderer.cpp:331-336). hdr_out/count_out are HOST
+ * buffers of w*h*3 doubles / w*h int32; pixels outside the rectangle are 0. */
+int ptamd_render(ptamd_context *ctx, const ptamd_render_params *p, double *hdr_out, int32_t *count_out);
+
+/* Closest hit of camera rays through normalised sensor positions (sx, sy) in
+ * [0,1]^2: Camera::generate_ray + BVHAccel::intersect (camera.cpp:190-203,
+ * src/scene/bvh.cpp:164-200). prim_out is the primitive's index in desc order
+ * (-1 = miss); t_out the hit distance. Host buffers of n entries. */
+int ptamd_trace_primary(ptamd_context *ctx, int64_t n, const double *sx, const double *sy,
+                        int32_t *prim_out, double *t_out);
+
+/* ---- round-level API (multi-GPU drivers shard pixels between rounds) -------
+ * A frame is rendered in rounds of `samples_per_batch` samples per still-active
+ * pixel, as raytrace_pixel's loop does (pathtracer.cpp:249-267). All pointers in
+ * this group are DEVICE pointers; `stream` is a hipStream_t (NULL = default).
+ *
+ * Per-pixel state is 6 doubles per pixel, [w*h*6]: s1, s2, sum.r, sum.g, sum.b,
+ * n (sample count as a double), indexed by pixel. */
+int ptamd_frame_begin(ptamd_context *ctx, const ptamd_render_params *p);
+/* Traces samples [sample_base, sample_base + n_samples) of the n listed pixels
+ * and adds them to `state`. pixels: int32 pixel indices. */
+int ptamd_trace_pixels(ptamd_context *ctx, const int32_t *d_pixels, int64_t n, int32_t sample_base,
+                       int32_t n_samples, double *d_state, void *stream);
+/* The adaptive test of pathtracer.cpp:250-258 at i = n_done for the n listed
+ * pixels; survivors are written, in order, to d_pixels_out and their number to
+ * *d_n_out (one int64 on the device). */
+int ptamd_adaptive_filter(ptamd_context *ctx, const int32_t *d_pixels_in, int64_t n, int32_t n_done,
+                          const double *d_state, int32_t *d_pixels_out, int64_t *d_n_out, void *stream);
+/* pixel_sum / n and the sample count (pathtracer.cpp:268-271) for every pixel. */
+int ptamd_frame_resolve(ptamd_context *ctx, const double *d_state, double *d_hdr_out, int32_t *d_count_out,
+                        void *stream);
+
+int ptamd_get_stats(ptamd_context *ctx, ptamd_stats *out);
+
+/* ---- output stage (host) --------------------------------------------------
+ * HDRImageBuffer::toColor + ImageBuffer::update_pixel (src/util/image.h:183-198,
+ * 53-62): gamma 2.2, exposure sqrt(2), truncation to 8 bits, R in the low byte. */
+int ptamd_tonemap_rgba8(const double *hdr, int32_t w, int32_t h, uint32_t *rgba_out);
+/* save_image (raytraced_renderer.cpp:680-718): vertical flip, alpha = 255, PNG. */
+int ptamd_write_png(const char *path, const uint32_t *rgba_bottom_up, int32_t w, int32_t h);
+/* save_sampling_rate_image (raytraced_renderer.cpp:720-751) as RGBA8, top row first. */
+int ptamd_sampling_rate_rgba8(const int32_t *count, int32_t w, int32_t h, int32_t ns_aa, uint32_t *rgba_top_down);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTAMD_H */

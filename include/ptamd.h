@@ -193,6 +193,8 @@ int ptamd_get_stats(ptamd_context *ctx, ptamd_stats *out);
 int ptamd_tonemap_rgba8(const double *hdr, int32_t w, int32_t h, uint32_t *rgba_out);
 /* save_image (raytraced_renderer.cpp:680-718): vertical flip, alpha = 255, PNG. */
 int ptamd_write_png(const char *path, const uint32_t *rgba_bottom_up, int32_t w, int32_t h);
+/* Same encoder without the flip (used for the sampling-rate map). */
+int ptamd_write_png_top_down(const char *path, const uint32_t *rgba_top_down, int32_t w, int32_t h);
 /* save_sampling_rate_image (raytraced_renderer.cpp:720-751) as RGBA8, top row first. */
 int ptamd_sampling_rate_rgba8(const int32_t *count, int32_t w, int32_t h, int32_t ns_aa, uint32_t *rgba_top_down);
 

@@ -1,0 +1,203 @@
+"""ctypes binding of the ptamd C ABI (include/ptamd.h)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import cabi
+from .cabi import Camera, RenderParams, SceneDesc, Stats, make_params  # noqa: F401
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+# every symbol include/ptamd.h declares
+EXPORTS = (
+    "ptamd_last_error", "ptamd_scene_load", "ptamd_scene_free", "ptamd_scene_get_desc",
+    "ptamd_scene_get_camera", "ptamd_scene_load_camera_file", "ptamd_scene_build_seconds",
+    "ptamd_create", "ptamd_destroy", "ptamd_upload_scene", "ptamd_set_camera", "ptamd_set_max_paths",
+    "ptamd_set_profiling", "ptamd_render", "ptamd_trace_primary", "ptamd_frame_begin",
+    "ptamd_trace_pixels", "ptamd_adaptive_filter", "ptamd_frame_resolve", "ptamd_get_stats",
+    "ptamd_tonemap_rgba8", "ptamd_write_png", "ptamd_write_png_top_down", "ptamd_sampling_rate_rgba8",
+)
+
+
+class PtamdError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return os.path.join(_HERE, "libptamd.so")
+
+
+def lib():
+    """Loads libptamd.so; raises PtamdError if it has not been built."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise PtamdError("%s is missing: build it with `make -C pathtracer_amd/csrc` "
+                         "(there is no CPU fallback for the render path)" % path)
+    L = C.CDLL(path)
+    vp, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+    pd, pi = C.POINTER(C.c_double), C.POINTER(C.c_int32)
+    L.ptamd_last_error.restype = C.c_char_p
+    L.ptamd_scene_load.argtypes = [C.c_char_p, C.POINTER(vp)]
+    L.ptamd_scene_free.argtypes = [vp]
+    L.ptamd_scene_free.restype = None
+    L.ptamd_scene_get_desc.argtypes = [vp, C.POINTER(SceneDesc)]
+    L.ptamd_scene_get_camera.argtypes = [vp, i32, i32, C.POINTER(Camera)]
+    L.ptamd_scene_load_camera_file.argtypes = [vp, C.c_char_p]
+    L.ptamd_scene_build_seconds.argtypes = [vp]
+    L.ptamd_scene_build_seconds.restype = dbl
+    L.ptamd_create.argtypes = [i32, C.POINTER(vp)]
+    L.ptamd_destroy.argtypes = [vp]
+    L.ptamd_destroy.restype = None
+    L.ptamd_upload_scene.argtypes = [vp, C.POINTER(SceneDesc)]
+    L.ptamd_set_camera.argtypes = [vp, C.POINTER(Camera)]
+    L.ptamd_set_max_paths.argtypes = [vp, i64]
+    L.ptamd_set_profiling.argtypes = [vp, i32, i32]
+    L.ptamd_render.argtypes = [vp, C.POINTER(RenderParams), pd, pi]
+    L.ptamd_trace_primary.argtypes = [vp, i64, pd, pd, pi, pd]
+    L.ptamd_frame_begin.argtypes = [vp, C.POINTER(RenderParams)]
+    L.ptamd_trace_pixels.argtypes = [vp, vp, i64, i32, i32, vp, vp]
+    L.ptamd_adaptive_filter.argtypes = [vp, vp, i64, i32, vp, vp, vp, vp]
+    L.ptamd_frame_resolve.argtypes = [vp, vp, vp, vp, vp]
+    L.ptamd_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    L.ptamd_tonemap_rgba8.argtypes = [pd, i32, i32, C.POINTER(C.c_uint32)]
+    L.ptamd_write_png.argtypes = [C.c_char_p, C.POINTER(C.c_uint32), i32, i32]
+    L.ptamd_write_png_top_down.argtypes = [C.c_char_p, C.POINTER(C.c_uint32), i32, i32]
+    L.ptamd_sampling_rate_rgba8.argtypes = [pi, i32, i32, i32, C.POINTER(C.c_uint32)]
+    _LIB = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise PtamdError("ptamd error %d: %s" % (rc, lib().ptamd_last_error().decode(errors="replace")))
+
+
+class Scene:
+    """Host scene: COLLADA file -> static scene -> BVH -> flat arrays."""
+
+    def __init__(self, dae_path):
+        self._h = C.c_void_p()
+        _check(lib().ptamd_scene_load(os.fsencode(dae_path), C.byref(self._h)))
+        self.desc = SceneDesc()
+        _check(lib().ptamd_scene_get_desc(self._h, C.byref(self.desc)))
+
+    def camera(self, w=0, h=0):
+        cam = Camera()
+        _check(lib().ptamd_scene_get_camera(self._h, w, h, C.byref(cam)))
+        return cam
+
+    def load_camera_file(self, path):
+        _check(lib().ptamd_scene_load_camera_file(self._h, os.fsencode(path)))
+
+    def arrays(self):
+        """Deep numpy copy of the flattened scene (cabi.SceneArrays)."""
+        return cabi.SceneArrays.from_desc(self.desc)
+
+    @property
+    def build_seconds(self):
+        return lib().ptamd_scene_build_seconds(self._h)
+
+    def close(self):
+        if self._h:
+            lib().ptamd_scene_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Device:
+    """One GPU's render context."""
+
+    def __init__(self, device_id=0):
+        self._h = C.c_void_p()
+        _check(lib().ptamd_create(device_id, C.byref(self._h)))
+        self._keep = None
+
+    def upload(self, scene):
+        """scene: Scene, cabi.SceneArrays or SceneDesc."""
+        desc = scene.desc if hasattr(scene, "desc") else scene
+        self._keep = scene
+        _check(lib().ptamd_upload_scene(self._h, C.byref(desc)))
+
+    def set_camera(self, cam):
+        _check(lib().ptamd_set_camera(self._h, C.byref(cam)))
+
+    def set_max_paths(self, n):
+        _check(lib().ptamd_set_max_paths(self._h, n))
+
+    def set_profiling(self, events=False, counters=False):
+        _check(lib().ptamd_set_profiling(self._h, int(events), int(counters)))
+
+    def render(self, params):
+        """Whole frame; returns (hdr[h,w,3] float64, count[h,w] int32), row 0 = bottom."""
+        hdr = np.zeros(params.w * params.h * 3, np.float64)
+        cnt = np.zeros(params.w * params.h, np.int32)
+        _check(lib().ptamd_render(self._h, C.byref(params), hdr.ctypes.data_as(C.POINTER(C.c_double)),
+                                  cnt.ctypes.data_as(C.POINTER(C.c_int32))))
+        return hdr.reshape(params.h, params.w, 3), cnt.reshape(params.h, params.w)
+
+    def trace_primary(self, sx, sy):
+        sx = np.ascontiguousarray(sx, np.float64).ravel()
+        sy = np.ascontiguousarray(sy, np.float64).ravel()
+        if sx.size != sy.size:
+            raise PtamdError("sx and sy differ in length")
+        ids = np.zeros(sx.size, np.int32)
+        ts = np.zeros(sx.size, np.float64)
+        pd = C.POINTER(C.c_double)
+        _check(lib().ptamd_trace_primary(self._h, sx.size, sx.ctypes.data_as(pd), sy.ctypes.data_as(pd),
+                                         ids.ctypes.data_as(C.POINTER(C.c_int32)), ts.ctypes.data_as(pd)))
+        return ids, ts
+
+    # ---- round-level API: arguments are device pointers (ints) -------------
+    def frame_begin(self, params):
+        _check(lib().ptamd_frame_begin(self._h, C.byref(params)))
+
+    def trace_pixels(self, d_pixels, n, sample_base, n_samples, d_state, stream=0):
+        _check(lib().ptamd_trace_pixels(self._h, d_pixels, n, sample_base, n_samples, d_state, stream))
+
+    def adaptive_filter(self, d_in, n, n_done, d_state, d_out, d_n_out, stream=0):
+        _check(lib().ptamd_adaptive_filter(self._h, d_in, n, n_done, d_state, d_out, d_n_out, stream))
+
+    def frame_resolve(self, d_state, d_hdr, d_count, stream=0):
+        _check(lib().ptamd_frame_resolve(self._h, d_state, d_hdr, d_count, stream))
+
+    def stats(self):
+        st = Stats()
+        _check(lib().ptamd_get_stats(self._h, C.byref(st)))
+        return st
+
+    def close(self):
+        if self._h:
+            lib().ptamd_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def tonemap(hdr):
+    """hdr[h,w,3] -> uint32[h,w] RGBA8 (R low byte), reference tone curve."""
+    h, w, _ = hdr.shape
+    a = np.ascontiguousarray(hdr, np.float64)
+    out = np.zeros(h * w, np.uint32)
+    _check(lib().ptamd_tonemap_rgba8(a.ctypes.data_as(C.POINTER(C.c_double)), w, h,
+                                     out.ctypes.data_as(C.POINTER(C.c_uint32))))
+    return out.reshape(h, w)
+
+
+def write_png(path, rgba_bottom_up):
+    h, w = rgba_bottom_up.shape
+    a = np.ascontiguousarray(rgba_bottom_up, np.uint32)
+    _check(lib().ptamd_write_png(os.fsencode(path), a.ctypes.data_as(C.POINTER(C.c_uint32)), w, h))

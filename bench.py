@@ -1,0 +1,247 @@
+#!/usr/bin/env python3
+"""Benchmark of the render hot path: path samples per second.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step is one full frame of the workload (default: the CBdragon stand-in, 800x600,
+1024 spp, 4 samples per area light, max depth 5, adaptive sampling 32 / 0.05, the
+reference's defaults). samples = sum of per-pixel sample counts, as the reference's
+sampleCountBuffer would hold them. Rank 0 prints ONE JSON line.
+
+The line also carries
+  roofline      for the dominant kernel: algorithmic bytes of its rays (per-ray
+                node visits and primitive tests counted by the CPU restatement of
+                the reference's traversal on a sample of the same workload) over
+                its HIP-event time, against the 8 TB/s HBM peak;
+  cpu_baseline  the reference's own renderer (its sources, built by
+                `make -C oracle ref`) timed on this host on a bounded cell of the
+                same frame.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--scene", default="dragon", help="dragon (stand-in), bunny, or a .dae path")
+    ap.add_argument("--width", type=int, default=800)
+    ap.add_argument("--height", type=int, default=600)
+    ap.add_argument("--spp", type=int, default=None)
+    ap.add_argument("--light-samples", type=int, default=4)
+    ap.add_argument("--depth", type=int, default=5)
+    ap.add_argument("--max-paths", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-spp", type=int, default=64)
+    return ap.parse_args()
+
+
+def resolve_scene(name, rank):
+    import make_standin_scene
+    if name == "dragon":
+        path = make_standin_scene.standin_path("dragon")
+        if rank == 0:
+            make_standin_scene.ensure("dragon")
+        return path, "CBdragon stand-in (CBempty box + 100k-triangle procedural knot; CBdragon.dae is absent from the reference checkout)", 1024
+    if name == "bunny":
+        return os.path.join(ROOT, "scenes", "CBbunny.dae"), "CBbunny.dae", 256
+    return name, os.path.basename(name), 1024
+
+
+def cpu_leg(scene_path, args, spp, threads_port):
+    """Reference renderer + CPU restatement on a bounded cell of the same frame."""
+    import numpy as np
+    import pathtracer_amd as pt
+    from pathtracer_amd import cabi, ptar
+    import oracle_lib as O
+    w, h = args.width, args.height
+    cw = 32
+    cx = w // 2 - cw // 2
+    sample = "cell x=%d..%d, y=0..%d of the %dx%d frame at %d spp (-l %d -m %d, adaptive 32/0.05)" % (
+        cx, cx + cw, h, w, h, args.cpu_spp, args.light_samples, args.depth)
+    out = {"sample": sample}
+    # the CPU restatement: counts the reference traversal's node visits / primitive tests
+    sc = pt.Scene(scene_path)
+    arr = sc.arrays()
+    cam = sc.camera(w, h)
+    p = cabi.make_params(w, h, ns_aa=args.cpu_spp, max_ray_depth=args.depth, ns_area_light=args.light_samples,
+                         rect=(cx, 0, cx + cw, h))
+    _, _, st = O.render(arr, cam, p, threads=threads_port)
+    ext_rays = st.rays - st.shadow_rays
+    out["port"] = {"value": st.samples / st.seconds, "cores": threads_port}
+    out["counts"] = {
+        "V_ext": (st.nodes_visited - st.shadow_nodes_visited) / max(ext_rays, 1),
+        "T_ext": (st.prim_tests - st.shadow_prim_tests) / max(ext_rays, 1),
+        "V_shadow": st.shadow_nodes_visited / max(st.shadow_rays, 1),
+        "T_shadow": st.shadow_prim_tests / max(st.shadow_rays, 1),
+        "rays_per_sample": st.rays / max(st.samples, 1),
+        "vertices_per_sample": st.path_vertices / max(st.samples, 1),
+        "shadow_fraction": st.shadow_rays / max(st.rays, 1),
+    }
+    # the reference itself
+    ref = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
+    if os.path.exists(ref):
+        tmp = os.path.join(ROOT, "gpurun_out", "bench_ref_cell.ptar")
+        os.makedirs(os.path.dirname(tmp), exist_ok=True)
+        threads_ref = 8  # the thread count of the reference's own benchmark command line
+        cmd = [ref, "render", "-s", str(args.cpu_spp), "-l", str(args.light_samples), "-m", str(args.depth),
+               "-t", str(threads_ref), "-r", str(w), str(h), "-p", str(cx), "0", str(cw), str(h), "-f", tmp, scene_path]
+        r = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900)
+        if r.returncode == 0:
+            s = ptar.load(tmp)["stats"]
+            out["reference"] = {"value": float(s[3] / s[0]), "cores": threads_ref}
+    return out
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+    import torch
+    import torch.distributed as dist
+    import pathtracer_amd as pt
+    from pathtracer_amd import cabi, distributed
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    scene_path, workload_name, default_spp = resolve_scene(args.scene, rank)
+    spp = args.spp or default_spp
+    if world > 1:
+        dist.barrier()
+    sc = pt.Scene(scene_path)
+    cam = sc.camera(args.width, args.height)
+    dev = pt.Device(local_rank)
+    dev.upload(sc)
+    dev.set_camera(cam)
+    if args.max_paths:
+        dev.set_max_paths(args.max_paths)
+    dev.set_profiling(events=True, counters=False)
+
+    def frame(seed):
+        p = cabi.make_params(args.width, args.height, ns_aa=spp, max_ray_depth=args.depth,
+                             ns_area_light=args.light_samples, seed=seed)
+        hdr, cnt = distributed.render_frame(dev, p, rank=rank, world=world, device=device)
+        return cnt
+
+    for i in range(args.warmup):
+        frame(1000 + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    total_samples = 0
+    agg = {"ms": [0.0] * 8, "launches": [0] * 8, "rays": 0, "shadow": 0, "vertices": 0}
+    for i in range(args.steps):
+        cnt = frame(i)
+        total_samples += int(cnt.sum().item())
+        st = dev.stats()  # this rank's share of the frame
+        for k in range(8):
+            agg["ms"][k] += st.kernel_ms[k]
+            agg["launches"][k] += st.launches[k]
+        agg["rays"] += st.rays
+        agg["shadow"] += st.shadow_rays
+        agg["vertices"] += st.path_vertices
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        value = total_samples / elapsed
+        line = {
+            "metric": "path samples/sec",
+            "value": value,
+            "unit": "samples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1000.0 * elapsed / max(args.steps, 1),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "%s %dx%d, %d spp, -l %d -m %d, adaptive 32/0.05" % (
+                workload_name, args.width, args.height, spp, args.light_samples, args.depth),
+                "samples_per_step": total_samples // max(args.steps, 1),
+                "parallelism": "pixels of each adaptive round dealt round-robin over %d GPU(s)" % world},
+        }
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                cpu = cpu_leg(scene_path, args, spp, threads_port=min(16, os.cpu_count() or 1))
+            except Exception as e:  # the baseline must never take the GPU number down with it
+                cpu = {"error": repr(e)}
+        # ---- roofline of the dominant kernel (rank 0's launches)
+        names = cabi.K_NAMES
+        dom = max(range(8), key=lambda k: agg["ms"][k])
+        roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
+                "traffic": None, "kernel": names[dom],
+                "kernel_ms": {names[k]: agg["ms"][k] for k in range(8) if agg["launches"][k]},
+                "launches": {names[k]: agg["launches"][k] for k in range(8) if agg["launches"][k]}}
+        if cpu and "counts" in cpu:
+            c = cpu["counts"]
+            ext_rays = agg["rays"] - agg["shadow"]
+            b_ext = 32 * c["V_ext"] + 36 * c["T_ext"] + 92
+            b_sh = 32 * c["V_shadow"] + 36 * c["T_shadow"] + 92
+            if dom in (1, 3):
+                rays = ext_rays if dom == 1 else agg["shadow"]
+                b = b_ext if dom == 1 else b_sh
+                ms = agg["ms"][dom]
+                ach = rays * b / (ms * 1e-3) / 1e9 if ms > 0 else None
+                roof.update({"achieved": ach, "frac": ach / HBM_PEAK_GBS if ach else None,
+                             "bytes_per_ray": b, "rays_per_launch": rays / max(agg["launches"][dom], 1),
+                             "avg_launch_ms": ms / max(agg["launches"][dom], 1)})
+            # whole-frame figure: samples/s x algorithmic bytes per sample
+            b_sample = (ext_rays * b_ext + agg["shadow"] * b_sh + 72 * agg["vertices"]) / max(total_samples, 1) + 16
+            roof["bytes_per_sample"] = b_sample
+            roof["frame_frac_of_hbm_peak"] = value * b_sample / 1e9 / (HBM_PEAK_GBS * world)
+            roof["counts"] = c
+        line["roofline"] = roof
+        if cpu and "reference" in cpu:
+            line["cpu_baseline"] = {"value": cpu["reference"]["value"], "unit": "samples/s",
+                                    "cores": cpu["reference"]["cores"], "kind": "reference", "sample": cpu["sample"],
+                                    "port_value": cpu["port"]["value"], "port_cores": cpu["port"]["cores"]}
+        elif cpu and "port" in cpu:
+            line["cpu_baseline"] = {"value": cpu["port"]["value"], "unit": "samples/s", "cores": cpu["port"]["cores"],
+                                    "kind": "port", "sample": cpu["sample"]}
+        elif cpu:
+            line["cpu_baseline"] = cpu
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -104,7 +104,8 @@ typedef struct {
   const ptamd_render_params *p;
   int nls; /* light samples per vertex */
   int bpv; /* RNG blocks per vertex */
-  uint64_t rays, shadow_rays, vertices, nodes, tests;
+  uint64_t rays, shadow_rays, vertices, nodes, tests, shadow_nodes, shadow_tests;
+  int in_shadow;
 } ctx_t;
 
 /* src/scene/bbox.cpp:10-47 */
@@ -188,11 +189,13 @@ static int bvh_intersect(ctx_t *c, ray_t *ray, isect_t *i) {
   while (sp > 0) {
     int n = stack[--sp];
     c->nodes++;
+    if (c->in_shadow) c->shadow_nodes++;
     if (!bbox_intersect(s->node_bbox + 6 * (size_t)n, ray, &t0, &t1)) continue;
     if (s->node_count[n] > 0) {
       int b = s->node_start[n], e = b + s->node_count[n];
       for (int p = b; p < e; p++) {
         c->tests++;
+        if (c->in_shadow) c->shadow_tests++;
         double t;
         v3 nn;
         int h = (s->prim_type[p] == PTAMD_PRIM_TRIANGLE)
@@ -379,7 +382,10 @@ static v3 estimate_direct_lighting_importance(ctx_t *c, const rng_t *g, const ra
       shadow_ray.max_t = distToLight;
       isect_t light_isect;
       c->shadow_rays++;
-      if (!bvh_intersect(c, &shadow_ray, &light_isect)) {
+      c->in_shadow = 1;
+      int occluded = bvh_intersect(c, &shadow_ray, &light_isect);
+      c->in_shadow = 0;
+      if (!occluded) {
         /* f * radiance * abs_cos_theta(wi_o) / pdf */
         v3 term = vdivs(vscale(vmul(bsdf_f(c, isect->material), radiance), fabs(wi_o.z)), pdf);
         L_out = vadd(L_out, term);
@@ -407,7 +413,10 @@ static v3 estimate_direct_lighting_hemisphere(ctx_t *c, const rng_t *g, const ra
     shadow_ray.min_t = EPS_D;
     isect_t light_isect;
     c->shadow_rays++;
-    if (bvh_intersect(c, &shadow_ray, &light_isect)) {
+    c->in_shadow = 1;
+    int found = bvh_intersect(c, &shadow_ray, &light_isect);
+    c->in_shadow = 0;
+    if (found) {
       v3 light_L = bsdf_emission(c, light_isect.material);
       /* f * light_L * dot(wi, w2o*isect.n) * 2 * PI */
       double cs = vdot(wi, mmul(&w2o, isect->n));
@@ -558,10 +567,10 @@ int oracle_render(const ptamd_scene_desc *scene, const ptamd_camera *cam, const 
   if (ntx < 0) ntx = 0;
   if (nty < 0) nty = 0;
   if (threads < 1) threads = 1;
-  uint64_t rays = 0, shadow = 0, verts = 0, nodes = 0, tests = 0;
+  uint64_t rays = 0, shadow = 0, verts = 0, nodes = 0, tests = 0, snodes = 0, stests = 0;
   double t_begin = now_s();
 #ifdef _OPENMP
-#pragma omp parallel num_threads(threads) reduction(+ : rays, shadow, verts, nodes, tests)
+#pragma omp parallel num_threads(threads) reduction(+ : rays, shadow, verts, nodes, tests, snodes, stests)
 #endif
   {
     ctx_t c;
@@ -576,11 +585,13 @@ int oracle_render(const ptamd_scene_desc *scene, const ptamd_camera *cam, const 
         for (int x = tx; x < ex; x++) raytrace_pixel(&c, x, y, hdr, count);
     }
     rays += c.rays; shadow += c.shadow_rays; verts += c.vertices; nodes += c.nodes; tests += c.tests;
+    snodes += c.shadow_nodes; stests += c.shadow_tests;
   }
   if (stats) {
     stats->seconds = now_s() - t_begin;
     stats->rays = rays; stats->shadow_rays = shadow; stats->path_vertices = verts;
     stats->nodes_visited = nodes; stats->prim_tests = tests; stats->threads = threads;
+    stats->shadow_nodes_visited = snodes; stats->shadow_prim_tests = stests;
     uint64_t total = 0;
     for (size_t i = 0; i < (size_t)p->w * p->h; i++) total += (uint64_t)count[i];
     stats->samples = total;

@@ -43,6 +43,7 @@ extern "C" {
 typedef struct oracle_stats {
   double seconds;
   uint64_t samples, rays, shadow_rays, path_vertices, nodes_visited, prim_tests;
+  uint64_t shadow_nodes_visited, shadow_prim_tests; /* the share of the two above spent on shadow rays */
   int32_t threads;
 } oracle_stats;
 

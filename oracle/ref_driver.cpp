@@ -172,6 +172,7 @@ struct Args {
   size_t samples_per_batch = 32;
   float max_tolerance = 0.05f;
   size_t w = 0, h = 0;
+  long cx = -1, cy = 0, cdx = 0, cdy = 0;  // -p cell
   std::string scene;
 };
 
@@ -538,6 +539,13 @@ void dump_render(RefApp *app, FILE *f, const Args &a) {
     // RaytracedRenderer::render_to_file minus the PNG write
     // (src/pathtracer/raytraced_renderer.cpp:331-336)
     std::unique_lock<std::mutex> lk(R->m_done);
+    if (a.cx >= 0) {
+      // the cell set-up of render_to_file / raytrace_cell
+      // (src/pathtracer/raytraced_renderer.cpp:339-343, 612-626)
+      R->render_cell = true;
+      R->cell_tl = Vector2D(a.cx, a.cy);
+      R->cell_br = Vector2D(a.cx + a.cdx, a.cy + a.cdy);
+    }
     R->start_raytracing();
     R->cv_done.wait(lk, [R] { return R->state == RaytracedRenderer::DONE; });
     lk.unlock();
@@ -569,7 +577,7 @@ void dump_render(RefApp *app, FILE *f, const Args &a) {
 void usage() {
   fprintf(stderr,
           "usage: ref_driver <dump|primary|render|kat> [-s spp -l light -m depth -o accum -t threads\n"
-          "                  -a batch tol -H -r W H] -f out.ptar [scene.dae]\n");
+          "                  -a batch tol -H -r W H -p x y dx dy] -f out.ptar [scene.dae]\n");
 }
 
 }  // namespace
@@ -582,7 +590,7 @@ int main(int argc, char **argv) {
   int opt;
   optind = 2;
   // same option letters and two-word handling as src/application/main.cpp:126-187
-  while ((opt = getopt(argc, argv, "s:l:t:m:o:f:r:a:H")) != -1) {
+  while ((opt = getopt(argc, argv, "s:l:t:m:o:f:r:a:Hp:")) != -1) {
     switch (opt) {
       case 'f': out = optarg; break;
       case 'r': a.w = atoi(argv[optind - 1]); a.h = atoi(argv[optind]); optind++; break;
@@ -593,6 +601,11 @@ int main(int argc, char **argv) {
       case 'o': a.accum = atoi(optarg) > 0; break;
       case 'a': a.samples_per_batch = atoi(argv[optind - 1]); a.max_tolerance = atof(argv[optind]); optind++; break;
       case 'H': a.hemisphere = true; break;
+      case 'p':
+        a.cx = atoi(argv[optind - 1]); a.cy = atoi(argv[optind]);
+        a.cdx = atoi(argv[optind + 1]); a.cdy = atoi(argv[optind + 2]);
+        optind += 3;
+        break;
       default: usage(); return 1;
     }
   }

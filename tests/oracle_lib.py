@@ -14,7 +14,8 @@ _LIB = None
 class OracleStats(C.Structure):
     _fields_ = [("seconds", C.c_double), ("samples", C.c_uint64), ("rays", C.c_uint64),
                 ("shadow_rays", C.c_uint64), ("path_vertices", C.c_uint64),
-                ("nodes_visited", C.c_uint64), ("prim_tests", C.c_uint64), ("threads", C.c_int32)]
+                ("nodes_visited", C.c_uint64), ("prim_tests", C.c_uint64),
+                ("shadow_nodes_visited", C.c_uint64), ("shadow_prim_tests", C.c_uint64), ("threads", C.c_int32)]
 
 
 def lib():

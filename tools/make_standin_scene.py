@@ -1,0 +1,136 @@
+#!/usr/bin/env python3
+"""Writes the documented stand-ins for the headline scenes that are absent from the
+reference checkout (dae/sky/CBdragon.dae, dae/sky/CBlucy.dae).
+
+A stand-in is the CBempty Cornell box (walls, area light, camera: copied from
+scenes/CBempty.dae) plus one closed, manifold, procedurally generated diffuse
+mesh of the requested size: the tube around a (2,3) torus knot with a smooth
+radial ripple. The mesh is deterministic (no random numbers), so every machine
+writes byte-identical files.
+
+    python tools/make_standin_scene.py dragon   # ~100k triangles -> scenes/_generated/CBdragon_standin.dae
+    python tools/make_standin_scene.py lucy     # ~133k triangles -> scenes/_generated/CBlucy_standin.dae
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PRESETS = {"dragon": (512, 98), "lucy": (640, 104), "tiny": (48, 12)}
+
+
+def knot_mesh(nu, nv):
+    """Vertices (world space: x right, y up, z towards the camera) and triangles."""
+    u = np.linspace(0.0, 2 * np.pi, nu, endpoint=False)
+    p, q = 2, 3
+    r = 0.30 + 0.12 * np.cos(q * u)
+    centre = np.stack([r * np.cos(p * u), 0.14 * np.sin(q * u), r * np.sin(p * u)], axis=1)
+    du = 2 * np.pi / nu
+    tangent = (np.roll(centre, -1, axis=0) - np.roll(centre, 1, axis=0)) / (2 * du)
+    tangent /= np.linalg.norm(tangent, axis=1, keepdims=True)
+    up = np.array([0.0, 1.0, 0.0])
+    n1 = np.cross(tangent, up)
+    n1 /= np.linalg.norm(n1, axis=1, keepdims=True)
+    n2 = np.cross(tangent, n1)
+    v = np.linspace(0.0, 2 * np.pi, nv, endpoint=False)
+    uu, vv = np.meshgrid(u, v, indexing="ij")
+    tube = 0.085 * (1.0 + 0.18 * np.sin(7 * uu + 3 * vv) + 0.10 * np.cos(11 * vv - 5 * uu))
+    pts = (centre[:, None, :] + tube[..., None] * (np.cos(vv)[..., None] * n1[:, None, :] + np.sin(vv)[..., None] * n2[:, None, :]))
+    pts = pts.reshape(-1, 3) + np.array([0.0, 0.62, -0.05])
+    idx = np.arange(nu * nv).reshape(nu, nv)
+    a = idx
+    b = np.roll(idx, -1, axis=0)
+    c = np.roll(np.roll(idx, -1, axis=0), -1, axis=1)
+    d = np.roll(idx, -1, axis=1)
+    tris = np.concatenate([np.stack([a, b, c], axis=-1).reshape(-1, 3), np.stack([a, c, d], axis=-1).reshape(-1, 3)])
+    return pts.astype(np.float32), tris
+
+
+def write_scene(kind, out_path):
+    nu, nv = PRESETS[kind]
+    pts, tris = knot_mesh(nu, nv)
+    with open(os.path.join(ROOT, "scenes", "CBempty.dae")) as f:
+        dae = f.read()
+    # the file is Z_UP: the loader maps (x, y, z) -> (-x, z, y); invert that here
+    dae_pts = np.stack([-pts[:, 0], pts[:, 2], pts[:, 1]], axis=1)
+    pos_txt = " ".join("%.7g" % x for x in dae_pts.ravel())
+    p_txt = " ".join(str(int(i)) for i in tris.ravel())
+    vcount = "3 " * len(tris)
+    effect = """    <effect id="standin-effect">
+      <profile_COMMON>
+        <technique sid="common">
+          <phong>
+            <diffuse>
+              <color sid="diffuse">0.7 0.62 0.45 1</color>
+            </diffuse>
+          </phong>
+        </technique>
+      </profile_COMMON>
+    </effect>
+"""
+    material = """    <material id="standin-material" name="standin">
+      <instance_effect url="#standin-effect"/>
+    </material>
+"""
+    geometry = """    <geometry id="standin-mesh" name="standin">
+      <mesh>
+        <source id="standin-mesh-positions">
+          <float_array id="standin-mesh-positions-array" count="%d">%s</float_array>
+          <technique_common>
+            <accessor source="#standin-mesh-positions-array" count="%d" stride="3">
+              <param name="X" type="float"/>
+              <param name="Y" type="float"/>
+              <param name="Z" type="float"/>
+            </accessor>
+          </technique_common>
+        </source>
+        <vertices id="standin-mesh-vertices">
+          <input semantic="POSITION" source="#standin-mesh-positions"/>
+        </vertices>
+        <polylist material="standin-material" count="%d">
+          <input semantic="VERTEX" source="#standin-mesh-vertices" offset="0"/>
+          <vcount>%s</vcount>
+          <p>%s</p>
+        </polylist>
+      </mesh>
+    </geometry>
+""" % (dae_pts.size, pos_txt, len(dae_pts), len(tris), vcount, p_txt)
+    node = """      <node id="standin" name="standin" type="NODE">
+        <matrix sid="transform">1 0 0 0 0 1 0 0 0 0 1 0 0 0 0 1</matrix>
+        <instance_geometry url="#standin-mesh">
+          <bind_material>
+            <technique_common>
+              <instance_material symbol="standin-material" target="#standin-material"/>
+            </technique_common>
+          </bind_material>
+        </instance_geometry>
+      </node>
+"""
+    dae = dae.replace("  </library_effects>", effect + "  </library_effects>", 1)
+    dae = dae.replace("  </library_materials>", material + "  </library_materials>", 1)
+    dae = dae.replace("  </library_geometries>", geometry + "  </library_geometries>", 1)
+    dae = dae.replace("    </visual_scene>", node + "    </visual_scene>", 1)
+    os.makedirs(os.path.dirname(out_path), exist_ok=True)
+    tmp = out_path + ".tmp%d" % os.getpid()
+    with open(tmp, "w") as f:
+        f.write(dae)
+    os.replace(tmp, out_path)
+    return len(tris)
+
+
+def standin_path(kind):
+    return os.path.join(ROOT, "scenes", "_generated", "CB%s_standin.dae" % kind)
+
+
+def ensure(kind):
+    path = standin_path(kind)
+    if not os.path.exists(path):
+        write_scene(kind, path)
+    return path
+
+
+if __name__ == "__main__":
+    k = sys.argv[1] if len(sys.argv) > 1 else "dragon"
+    n = write_scene(k, standin_path(k))
+    print("%s: %d triangles -> %s" % (k, n + 12, standin_path(k)))

@@ -103,19 +103,6 @@ struct PathBuf {
   double *pend[3];
 };
 
-// ------------------------------------------------------------------ wave helpers
-// Appends one item per flagged lane to a queue: one atomic per wave64.
-__device__ __forceinline__ uint32_t wave_append(uint32_t *counter, bool flag) {
-  unsigned long long mask = __ballot(flag);
-  if (mask == 0) return 0;
-  const int lane = __lane_id();
-  const int leader = __ffsll((long long)mask) - 1;
-  uint32_t base = 0;
-  if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
-  base = __shfl(base, leader);
-  return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-}
-
 // ------------------------------------------------------------------ intersection
 // BBox::intersect (src/scene/bbox.cpp:10-47) against the live max_t.
 __device__ __forceinline__ bool slab(const double *bb, v3 o, v3 inv, double min_t, double max_t, double &tmin_out) {
@@ -393,15 +380,21 @@ __global__ void k_generate_primary(FrameParams fp, const double *__restrict__ sx
   }
 }
 
+// Ray and vertex records live at FIXED positions (a bounce ray at its parent's
+// list position, light sample q of vertex i at slot i*nls + q) and the queues are
+// ordered index lists built by ballot / prefix-sum compaction: no atomics, and
+// the order is the same on every run.
 template <bool COUNT>
-__global__ void __launch_bounds__(256) k_extend(DevScene S, RayQ q, HitBuf hb, Ctl *ctl, double min_t, double max_t) {
+__global__ void __launch_bounds__(256)
+    k_extend(DevScene S, RayQ q, const int32_t *__restrict__ list, HitBuf hb, Ctl *ctl, double min_t, double max_t) {
   extern __shared__ uint2 stack[];
   const uint32_t n = ctl->n_cur;
   const uint32_t stride = gridDim.x * blockDim.x;
   uint32_t cn = 0, ct = 0;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const v3 o = V(q.o[0][i], q.o[1][i], q.o[2][i]);
-    const v3 d = V(q.d[0][i], q.d[1][i], q.d[2][i]);
+    const uint32_t j = list ? (uint32_t)list[i] : i;
+    const v3 o = V(q.o[0][j], q.o[1][j], q.o[2][j]);
+    const v3 d = V(q.d[0][j], q.d[1][j], q.d[2][j]);
     Hit h;
     traverse<false, COUNT>(S, o, d, min_t, max_t, h, stack, cn, ct);
     hb.prim[i] = h.prim;
@@ -417,7 +410,7 @@ __global__ void __launch_bounds__(256) k_extend(DevScene S, RayQ q, HitBuf hb, C
 
 // Shadow rays: light sampling needs only "is anything in the way"
 // (pathtracer.cpp:127); hemisphere sampling needs the closest hit's emission
-// (pathtracer.cpp:79-82).
+// (pathtracer.cpp:79-82). vis[slot]: 2 = ray pending, 1 = light sample counts, 0 = not.
 template <bool HEMI, bool COUNT>
 __global__ void __launch_bounds__(256)
     k_shadow(DevScene S, ShadowQ sq, VertexBuf vb, Ctl *ctl, int32_t nls) {
@@ -429,11 +422,11 @@ __global__ void __launch_bounds__(256)
     const int32_t slot = sq.slot[i];
     const uint32_t e = (uint32_t)slot / (uint32_t)nls;
     const v3 o = V(vb.hp[0][e], vb.hp[1][e], vb.hp[2][e]);
-    const v3 d = V(sq.d[0][i], sq.d[1][i], sq.d[2][i]);
+    const v3 d = V(sq.d[0][slot], sq.d[1][slot], sq.d[2][slot]);
     Hit h;
     if (!HEMI) {
-      const bool occluded = traverse<true, COUNT>(S, o, d, PT_EPS_D, sq.max_t[i], h, stack, cn, ct);
-      if (!occluded) vb.vis[slot] = 1;
+      const bool occluded = traverse<true, COUNT>(S, o, d, PT_EPS_D, sq.max_t[slot], h, stack, cn, ct);
+      vb.vis[slot] = occluded ? 0 : 1;
     } else {
       const bool found = traverse<false, COUNT>(S, o, d, PT_EPS_D, (double)INFINITY, h, stack, cn, ct);
       if (found) {
@@ -442,10 +435,10 @@ __global__ void __launch_bounds__(256)
         if (S.mat_kind[m] == PTAMD_MAT_EMISSION) light_L = V(S.mat_param[3 * m], S.mat_param[3 * m + 1], S.mat_param[3 * m + 2]);
         // f * light_L * dot(wi, w2o*n) * 2 * PI; f waits in the contrib slot, the cosine in max_t
         const v3 f = V(vb.contrib[0][slot], vb.contrib[1][slot], vb.contrib[2][slot]);
-        const v3 term = vscale(vscale(vscale(vmul(f, light_L), sq.max_t[i]), 2), PT_PI);
+        const v3 term = vscale(vscale(vscale(vmul(f, light_L), sq.max_t[slot]), 2), PT_PI);
         vb.contrib[0][slot] = term.x; vb.contrib[1][slot] = term.y; vb.contrib[2][slot] = term.z;
-        vb.vis[slot] = 1;
       }
+      vb.vis[slot] = found ? 1 : 0;
     }
   }
   if (COUNT) {
@@ -454,15 +447,25 @@ __global__ void __launch_bounds__(256)
   }
 }
 
-// One thread per queue entry at path depth `depth` (1 = camera ray's hit).
-// Restates at_least_one_bounce_radiance (pathtracer.cpp:160-201) iteratively:
-// the path carries its throughput T, every shaded vertex adds T * direct light.
+struct Compact {
+  uint8_t *pflag;        // [cap] entry pushes a bounce ray
+  uint32_t *cnt_next;    // [cap/256 + 1] bounce rays per 256-entry block, then their exclusive scan
+  uint32_t *cnt_shadow;  // [cap/256 + 1] shadow rays per 256-entry block, then their exclusive scan
+};
+
+// One thread per entry of the current list at path depth `depth` (1 = the camera
+// ray's hit). Restates at_least_one_bounce_radiance (pathtracer.cpp:160-201)
+// iteratively: the path carries its throughput T, every shaded vertex adds
+// T * direct light.
 __global__ void __launch_bounds__(256)
-    k_shade(FrameParams fp, DevScene S, RayQ q, HitBuf hb, RayQ qn, ShadowQ sq, VertexBuf vb, PathBuf pb, Ctl *ctl,
-            int32_t depth, const int32_t *__restrict__ pixels, int32_t sample_base, int32_t ns) {
+    k_shade(FrameParams fp, DevScene S, RayQ q, const int32_t *__restrict__ list, HitBuf hb, RayQ qn, ShadowQ sq,
+            VertexBuf vb, PathBuf pb, Compact cp, Ctl *ctl, int32_t depth, const int32_t *__restrict__ pixels,
+            int32_t sample_base, int32_t ns) {
+  __shared__ uint32_t wsum[2][4];
   const uint32_t n = ctl->n_cur;
   const uint32_t stride = gridDim.x * blockDim.x;
   const int nls = fp.nls;
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   for (uint32_t base_i = blockIdx.x * blockDim.x; base_i < n; base_i += stride) {
     const uint32_t i = base_i + threadIdx.x;
     const bool valid = i < n;
@@ -473,10 +476,11 @@ __global__ void __launch_bounds__(256)
     o2w.c[0] = o2w.c[1] = o2w.c[2] = V(0, 0, 0);
     w2o = o2w;
     int32_t path = 0;
-    uint32_t rng_s = 0, rng_pix = 0, rng_base = 0;
+    uint32_t rng_s = 0, rng_pix = 0, rng_base = 0, n_emit = 0;
     if (valid) {
+      const uint32_t j = list ? (uint32_t)list[i] : i;
       const int32_t prim = hb.prim[i];
-      path = q.path[i];
+      path = q.path[j];
       if (prim < 0) {
         // bounce ray left the scene: without accumulation the vertex before it
         // keeps its direct light (pathtracer.cpp:196-198)
@@ -490,8 +494,8 @@ __global__ void __launch_bounds__(256)
         const int32_t info = S.prim_info[prim];
         const int32_t mat = info >> 1;
         const int32_t kind = S.mat_kind[mat];
-        const v3 ro = V(q.o[0][i], q.o[1][i], q.o[2][i]);
-        const v3 rd = V(q.d[0][i], q.d[1][i], q.d[2][i]);
+        const v3 ro = V(q.o[0][j], q.o[1][j], q.o[2][j]);
+        const v3 rd = V(q.d[0][j], q.d[1][j], q.d[2][j]);
         const double t = hb.t[i];
         if (!(info & 1)) {
           // (1 - u - v) * n1 + u * n2 + v * n3, src/scene/triangle.cpp:66
@@ -515,7 +519,7 @@ __global__ void __launch_bounds__(256)
             pb.rad[2][path] += S.mat_param[3 * mat + 2];
           }
         } else {
-          T = V(q.T[0][i], q.T[1][i], q.T[2][i]);
+          T = V(q.T[0][j], q.T[1][j], q.T[2][j]);
           if (!fp.accum) { pb.pend[0][path] = 0; pb.pend[1][path] = 0; pb.pend[2][path] = 0; }
         }
         uint8_t flag = 0;
@@ -541,7 +545,7 @@ __global__ void __launch_bounds__(256)
           // samples and its bounce are skipped (the reference traces them and
           // multiplies by zero)
           const bool lit = kind == PTAMD_MAT_DIFFUSE;
-          do_nee = lit;
+          do_nee = lit && nls > 0;
           if (do_nee) flag = 1 | ((!fp.accum && not_terminate) ? 2 : 0);
           if (not_terminate && lit) {
             double pdf;
@@ -555,106 +559,185 @@ __global__ void __launch_bounds__(256)
         vb.flag[i] = flag;
         if (flag) { vb.hp[0][i] = hit_p.x; vb.hp[1][i] = hit_p.y; vb.hp[2][i] = hit_p.z; }
       }
+      cp.pflag[i] = push ? 1 : 0;
     }
-    // ---- light samples -> shadow-ray queue (estimate_direct_lighting_*, pathtracer.cpp:47-135)
-    if (__ballot(do_nee)) {
+    // ---- light samples into their slots (estimate_direct_lighting_*, pathtracer.cpp:47-135)
+    if (do_nee) {
       int qq = 0;
       if (!fp.hemisphere) {
         for (int li = 0; li < S.n_lights; li++) {
           const int nsamp = light_is_delta(S.light_kind[li]) ? 1 : fp.ns_area_light;
-          for (int j = 0; j < nsamp; j++, qq++) {
-            bool emit = false;
-            v3 wi = V(0, 0, 0), term = V(0, 0, 0);
-            double dist = 0;
-            if (do_nee) {
-              uint32_t wd[4];
-              philox4x32_10(rng_s, rng_base + 1u + (uint32_t)(qq >> 1), fp.seed_hi, 0u, fp.seed_lo, rng_pix, wd);
-              const double sx = u01(wd[2 * (qq & 1)]), sy = u01(wd[2 * (qq & 1) + 1]);
-              double pdf;
-              const v3 radiance = light_sample_L(S, li, hit_p, sx, sy, wi, dist, pdf);
-              const v3 wi_o = mmul(w2o, wi);
-              if (!(wi_o.z < 0 || (radiance.x == 0 && radiance.y == 0 && radiance.z == 0))) {
-                emit = true;
-                term = vdivs(vscale(vmul(f, radiance), fabs(wi_o.z)), pdf);
-              }
-              vb.vis[(size_t)i * nls + qq] = 0;
-            }
-            const uint32_t si = wave_append(&ctl->n_shadow, emit);
-            if (emit) {
-              const int32_t slot = (int32_t)(i * (uint32_t)nls + (uint32_t)qq);
-              sq.slot[si] = slot;
-              sq.d[0][si] = wi.x; sq.d[1][si] = wi.y; sq.d[2][si] = wi.z;
-              sq.max_t[si] = dist;
+          for (int jj = 0; jj < nsamp; jj++, qq++) {
+            uint32_t wd[4];
+            philox4x32_10(rng_s, rng_base + 1u + (uint32_t)(qq >> 1), fp.seed_hi, 0u, fp.seed_lo, rng_pix, wd);
+            const double sx = u01(wd[2 * (qq & 1)]), sy = u01(wd[2 * (qq & 1) + 1]);
+            double pdf, dist;
+            v3 wi;
+            const v3 radiance = light_sample_L(S, li, hit_p, sx, sy, wi, dist, pdf);
+            const v3 wi_o = mmul(w2o, wi);
+            const size_t slot = (size_t)i * nls + qq;
+            if (!(wi_o.z < 0 || (radiance.x == 0 && radiance.y == 0 && radiance.z == 0))) {
+              const v3 term = vdivs(vscale(vmul(f, radiance), fabs(wi_o.z)), pdf);
+              sq.d[0][slot] = wi.x; sq.d[1][slot] = wi.y; sq.d[2][slot] = wi.z;
+              sq.max_t[slot] = dist;
               vb.contrib[0][slot] = term.x; vb.contrib[1][slot] = term.y; vb.contrib[2][slot] = term.z;
+              vb.vis[slot] = 2;
+              n_emit++;
+            } else {
+              vb.vis[slot] = 0;
             }
           }
         }
       } else {
         for (qq = 0; qq < nls; qq++) {
-          v3 wd3 = V(0, 0, 0);
-          double cs = 0;
-          if (do_nee) {
-            uint32_t wd[4];
-            philox4x32_10(rng_s, rng_base + 1u + (uint32_t)(qq >> 1), fp.seed_hi, 0u, fp.seed_lo, rng_pix, wd);
-            const v3 wi = uniform_hemisphere_sample(u01(wd[2 * (qq & 1)]), u01(wd[2 * (qq & 1) + 1]));
-            wd3 = mmul(o2w, wi);
-            cs = vdot(wi, mmul(w2o, n_sh));
-            vb.vis[(size_t)i * nls + qq] = 0;
-          }
-          const uint32_t si = wave_append(&ctl->n_shadow, do_nee);
-          if (do_nee) {
-            const int32_t slot = (int32_t)(i * (uint32_t)nls + (uint32_t)qq);
-            sq.slot[si] = slot;
-            sq.d[0][si] = wd3.x; sq.d[1][si] = wd3.y; sq.d[2][si] = wd3.z;
-            sq.max_t[si] = cs;
-            vb.contrib[0][slot] = f.x; vb.contrib[1][slot] = f.y; vb.contrib[2][slot] = f.z;
-          }
+          uint32_t wd[4];
+          philox4x32_10(rng_s, rng_base + 1u + (uint32_t)(qq >> 1), fp.seed_hi, 0u, fp.seed_lo, rng_pix, wd);
+          const v3 wi = uniform_hemisphere_sample(u01(wd[2 * (qq & 1)]), u01(wd[2 * (qq & 1) + 1]));
+          const v3 wd3 = mmul(o2w, wi);
+          const double cs = vdot(wi, mmul(w2o, n_sh));
+          const size_t slot = (size_t)i * nls + qq;
+          sq.d[0][slot] = wd3.x; sq.d[1][slot] = wd3.y; sq.d[2][slot] = wd3.z;
+          sq.max_t[slot] = cs;
+          vb.contrib[0][slot] = f.x; vb.contrib[1][slot] = f.y; vb.contrib[2][slot] = f.z;
+          vb.vis[slot] = 2;
+          n_emit++;
         }
       }
+    } else if (valid && nls > 0) {
+      for (int qq = 0; qq < nls; qq++) vb.vis[(size_t)i * nls + qq] = 0;
     }
-    // ---- bounce ray -> next queue (wave64 ballot + prefix compaction)
-    const uint32_t ni = wave_append(&ctl->n_next, push);
+    // ---- bounce ray at this entry's position in the next ray arrays
     if (push) {
-      qn.path[ni] = path;
-      qn.o[0][ni] = hit_p.x; qn.o[1][ni] = hit_p.y; qn.o[2][ni] = hit_p.z;
-      qn.d[0][ni] = next_d.x; qn.d[1][ni] = next_d.y; qn.d[2][ni] = next_d.z;
-      qn.T[0][ni] = next_T.x; qn.T[1][ni] = next_T.y; qn.T[2][ni] = next_T.z;
+      qn.path[i] = path;
+      qn.o[0][i] = hit_p.x; qn.o[1][i] = hit_p.y; qn.o[2][i] = hit_p.z;
+      qn.d[0][i] = next_d.x; qn.d[1][i] = next_d.y; qn.d[2][i] = next_d.z;
+      qn.T[0][i] = next_T.x; qn.T[1][i] = next_T.y; qn.T[2][i] = next_T.z;
     }
+    // ---- per-block counts for the compaction: wave64 ballot / reduction, then LDS
+    const unsigned long long pm = __ballot(push);
+    uint32_t em = n_emit;
+    for (int off = 32; off > 0; off >>= 1) em += __shfl_down(em, off);
+    if (lane == 0) { wsum[0][wv] = (uint32_t)__popcll(pm); wsum[1][wv] = em; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const uint32_t vbk = base_i >> 8;
+      cp.cnt_next[vbk] = wsum[0][0] + wsum[0][1] + wsum[0][2] + wsum[0][3];
+      cp.cnt_shadow[vbk] = wsum[1][0] + wsum[1][1] + wsum[1][2] + wsum[1][3];
+    }
+    __syncthreads();
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    // shaded vertices of this depth = hits; counted by resolve-free bookkeeping
+}
+
+// Exclusive scan of the two per-block count arrays (one workgroup); the totals
+// become the sizes of the next ray list and of the shadow-ray list.
+__global__ void __launch_bounds__(1024) k_scan2(Compact cp, Ctl *ctl) {
+  __shared__ uint32_t tmp[2][1024];
+  __shared__ uint32_t carry[2];
+  const uint32_t n_blocks = (ctl->n_cur + 255u) >> 8;
+  if (threadIdx.x < 2) carry[threadIdx.x] = 0;
+  __syncthreads();
+  for (uint32_t base = 0; base < n_blocks; base += 1024) {
+    const uint32_t i = base + threadIdx.x;
+    const uint32_t a = i < n_blocks ? cp.cnt_next[i] : 0, b = i < n_blocks ? cp.cnt_shadow[i] : 0;
+    tmp[0][threadIdx.x] = a;
+    tmp[1][threadIdx.x] = b;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024; off <<= 1) {
+      const uint32_t x = threadIdx.x >= off ? tmp[0][threadIdx.x - off] : 0;
+      const uint32_t y = threadIdx.x >= off ? tmp[1][threadIdx.x - off] : 0;
+      __syncthreads();
+      tmp[0][threadIdx.x] += x;
+      tmp[1][threadIdx.x] += y;
+      __syncthreads();
+    }
+    if (i < n_blocks) {
+      cp.cnt_next[i] = carry[0] + tmp[0][threadIdx.x] - a;
+      cp.cnt_shadow[i] = carry[1] + tmp[1][threadIdx.x] - b;
+    }
+    __syncthreads();
+    if (threadIdx.x == 1023) { carry[0] += tmp[0][1023]; carry[1] += tmp[1][1023]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    ctl->n_next = carry[0];
+    ctl->n_shadow = carry[1];
+  }
+}
+
+// Writes the two ordered index lists from the flags and the scanned block offsets.
+__global__ void __launch_bounds__(256)
+    k_scatter(Compact cp, VertexBuf vb, int32_t *__restrict__ list_next, ShadowQ sq, Ctl *ctl, int32_t nls) {
+  __shared__ uint32_t wcnt[4];
+  const uint32_t n = ctl->n_cur;
+  const uint32_t n_blocks = (n + 255u) >> 8;
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  for (uint32_t vbk = blockIdx.x; vbk < n_blocks; vbk += gridDim.x) {
+    const uint32_t i = (vbk << 8) + threadIdx.x;
+    // bounce rays
+    {
+      const bool keep = i < n && cp.pflag[i];
+      const unsigned long long m = __ballot(keep);
+      if (lane == 0) wcnt[wv] = (uint32_t)__popcll(m);
+      __syncthreads();
+      uint32_t off = cp.cnt_next[vbk];
+      for (int k = 0; k < wv; k++) off += wcnt[k];
+      if (keep) list_next[off + (uint32_t)__popcll(m & below)] = (int32_t)i;
+      __syncthreads();
+    }
+    // shadow rays, in slot order (vertex-major: the samples of one vertex stay adjacent)
+    uint32_t run = cp.cnt_shadow[vbk];
+    const size_t slot0 = (size_t)(vbk << 8) * nls, slot_end = (size_t)n * nls;
+    for (int c = 0; c < nls; c++) {
+      const size_t s = slot0 + (size_t)c * 256 + threadIdx.x;
+      const bool keep = s < slot_end && s < slot0 + (size_t)256 * nls && vb.vis[s] == 2;
+      const unsigned long long m = __ballot(keep);
+      if (lane == 0) wcnt[wv] = (uint32_t)__popcll(m);
+      __syncthreads();
+      uint32_t off = run;
+      for (int k = 0; k < wv; k++) off += wcnt[k];
+      if (keep) sq.slot[off + (uint32_t)__popcll(m & below)] = (int32_t)s;
+      run += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+      __syncthreads();
+    }
   }
 }
 
 // L_out = sum of the unoccluded samples in sampling order, then / sample_count
 // (pathtracer.cpp:116-134, 85); the path gains T * L_out.
-__global__ void k_resolve(FrameParams fp, RayQ q, VertexBuf vb, PathBuf pb, Ctl *ctl, int32_t depth) {
+__global__ void k_resolve(FrameParams fp, RayQ q, const int32_t *__restrict__ list, VertexBuf vb, PathBuf pb, Ctl *ctl,
+                          int32_t depth) {
   const uint32_t n = ctl->n_cur;
   const uint32_t stride = gridDim.x * blockDim.x;
   const int nls = fp.nls;
   unsigned long long verts = 0;
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const uint8_t flag = vb.flag[i];
-    if (!flag) continue;
-    verts++;
-    v3 L = V(0, 0, 0);
-    const size_t b = (size_t)i * nls;
-    for (int qq = 0; qq < nls; qq++) {
-      if (vb.vis[b + qq]) L = vadd(L, V(vb.contrib[0][b + qq], vb.contrib[1][b + qq], vb.contrib[2][b + qq]));
-    }
-    L = vscale(L, 1. / (double)nls);
-    const v3 T = depth == 1 ? V(1, 1, 1) : V(q.T[0][i], q.T[1][i], q.T[2][i]);
-    const v3 val = vmul(T, L);
-    const int32_t path = q.path[i];
-    if (flag & 2) {
-      pb.pend[0][path] = val.x; pb.pend[1][path] = val.y; pb.pend[2][path] = val.z;
-    } else {
-      pb.rad[0][path] += val.x; pb.rad[1][path] += val.y; pb.rad[2][path] += val.z;
+  for (uint32_t base_i = blockIdx.x * blockDim.x; base_i < n; base_i += stride) {
+    const uint32_t i = base_i + threadIdx.x;
+    if (i < n) {
+      const uint8_t flag = vb.flag[i];
+      if (flag) {
+        verts++;
+        v3 L = V(0, 0, 0);
+        const size_t b = (size_t)i * nls;
+        for (int qq = 0; qq < nls; qq++) {
+          if (vb.vis[b + qq] == 1) L = vadd(L, V(vb.contrib[0][b + qq], vb.contrib[1][b + qq], vb.contrib[2][b + qq]));
+        }
+        L = vscale(L, 1. / (double)nls);
+        const uint32_t j = list ? (uint32_t)list[i] : i;
+        const v3 T = depth == 1 ? V(1, 1, 1) : V(q.T[0][j], q.T[1][j], q.T[2][j]);
+        const v3 val = vmul(T, L);
+        const int32_t path = q.path[j];
+        if (flag & 2) {
+          pb.pend[0][path] = val.x; pb.pend[1][path] = val.y; pb.pend[2][path] = val.z;
+        } else {
+          pb.rad[0][path] += val.x; pb.rad[1][path] += val.y; pb.rad[2][path] += val.z;
+        }
+      }
     }
   }
   // one add per wave
   for (int off = 32; off > 0; off >>= 1) verts += __shfl_down(verts, off);
-  if (__lane_id() == 0 && verts) atomicAdd(&ctl->st_vertices, verts);
+  if ((threadIdx.x & 63) == 0 && verts) atomicAdd(&ctl->st_vertices, verts);
 }
 
 // Vector3D::illum (CGL/include/CGL/vector3D.h:231-233): double arithmetic, float result
@@ -799,6 +882,8 @@ struct ptamd_context {
   bool cap_pend = false;
   void *slab = nullptr;
   RayQ q[2]{};
+  int32_t *list[2]{nullptr, nullptr};
+  Compact cp{};
   HitBuf hb{};
   ShadowQ sq{};
   VertexBuf vb{};
@@ -883,7 +968,7 @@ int ensure_buffers(ptamd_context *c, int64_t paths, int nls, bool pend) {
   auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
   size_t total = 0;
   auto take = [&](size_t bytes) { size_t o = total; total += al(bytes); return o; };
-  size_t off_q[2][10], off_hit[4], off_sq[5], off_vb[8], off_pb[6];
+  size_t off_q[2][10], off_hit[4], off_sq[5], off_vb[8], off_pb[6], off_list[2], off_cp[3];
   for (int k = 0; k < 2; k++) {
     off_q[k][0] = take(P * 4);
     for (int j = 1; j < 10; j++) off_q[k][j] = take(P * 8);
@@ -897,6 +982,10 @@ int ensure_buffers(ptamd_context *c, int64_t paths, int nls, bool pend) {
   for (int j = 4; j < 7; j++) off_vb[j] = take(PN * 8);
   off_vb[7] = take(PN);
   for (int j = 0; j < 6; j++) off_pb[j] = take(P * 8);
+  for (int k = 0; k < 2; k++) off_list[k] = take(P * 4);
+  off_cp[0] = take(P);
+  off_cp[1] = take((P / 256 + 2) * 4);
+  off_cp[2] = take((P / 256 + 2) * 4);
   size_t off_ctl = take(sizeof(Ctl));
   HIPCHK(hipMalloc(&c->slab, total));
   char *b = (char *)c->slab;
@@ -923,6 +1012,10 @@ int ensure_buffers(ptamd_context *c, int64_t paths, int nls, bool pend) {
     c->pb.rad[j] = (double *)(b + off_pb[j]);
     c->pb.pend[j] = (double *)(b + off_pb[3 + j]);
   }
+  for (int k = 0; k < 2; k++) c->list[k] = (int32_t *)(b + off_list[k]);
+  c->cp.pflag = (uint8_t *)(b + off_cp[0]);
+  c->cp.cnt_next = (uint32_t *)(b + off_cp[1]);
+  c->cp.cnt_shadow = (uint32_t *)(b + off_cp[2]);
   c->ctl = (Ctl *)(b + off_ctl);
   HIPCHK(hipMemset(c->ctl, 0, sizeof(Ctl)));
   c->cap_paths = paths;
@@ -1165,6 +1258,10 @@ int ptamd_frame_begin(ptamd_context *c, const ptamd_render_params *p) {
   c->fp.nls = light_samples_per_vertex(c, p, c->host_light_kinds);
   c->fp.bpv = 1 + (c->fp.nls + 1) / 2;
   c->have_frame = true;
+  if (!c->events.empty()) {
+    HIPCHK(hipDeviceSynchronize());
+    collect_events(c);  // timings of earlier frames are not part of this one
+  }
   memset(&c->stats, 0, sizeof c->stats);
   if (c->ctl) HIPCHK(hipMemset(c->ctl, 0, sizeof(Ctl)));
   return PTAMD_OK;
@@ -1196,7 +1293,11 @@ int ptamd_trace_pixels(ptamd_context *c, const int32_t *d_pixels, int64_t n, int
   size_t lds = 0;
   const int tblock = traversal_block(c, &lds);
   if (lds > 160 * 1024) { ptamd::set_error("BVH too deep for the per-lane traversal stack"); return PTAMD_ERR_SCENE; }
-  const int tgrid = c->num_cu * std::max(1, (int)std::min<size_t>(8, (96 * 1024) / std::max<size_t>(lds, 1)) * (256 / tblock));
+  // resident workgroups per CU: bounded by the LDS stacks (160 KiB per CU) and by
+  // registers (about 5 waves per SIMD); twice that many workgroups in the grid so
+  // that the tail of a launch still has work to balance
+  const int wg_per_cu = std::max(1, std::min<int>((int)((160 * 1024) / std::max<size_t>(lds, 1)), 20 * 64 / tblock));
+  const int tgrid = c->num_cu * wg_per_cu * 2;
   const int ggrid = grid_for(c, 8);
   PathBuf pb = c->pb;
   if (fp.accum) pb.pend[0] = pb.pend[1] = pb.pend[2] = nullptr;
@@ -1216,13 +1317,18 @@ int ptamd_trace_pixels(ptamd_context *c, const int32_t *d_pixels, int64_t n, int
     for (int depth = 1; depth <= depths; depth++) {
       const double min_t = depth == 1 ? fp.n_clip : PT_EPS_D;
       const double max_t = depth == 1 ? fp.f_clip : (double)INFINITY;
+      const int32_t *lst = depth == 1 ? nullptr : c->list[cur];
       L.begin(PTAMD_K_EXTEND);
-      if (c->prof_counters) hipLaunchKernelGGL(k_extend<true>, tgrid, tblock, lds, s, c->S, c->q[cur], c->hb, c->ctl, min_t, max_t);
-      else hipLaunchKernelGGL(k_extend<false>, tgrid, tblock, lds, s, c->S, c->q[cur], c->hb, c->ctl, min_t, max_t);
+      if (c->prof_counters) hipLaunchKernelGGL(k_extend<true>, tgrid, tblock, lds, s, c->S, c->q[cur], lst, c->hb, c->ctl, min_t, max_t);
+      else hipLaunchKernelGGL(k_extend<false>, tgrid, tblock, lds, s, c->S, c->q[cur], lst, c->hb, c->ctl, min_t, max_t);
       L.end();
       L.begin(PTAMD_K_SHADE);
-      hipLaunchKernelGGL(k_shade, ggrid, 256, 0, s, fp, c->S, c->q[cur], c->hb, c->q[cur ^ 1], c->sq, c->vb, pb, c->ctl,
-                         depth, pix, sample_base, n_samples);
+      hipLaunchKernelGGL(k_shade, ggrid, 256, 0, s, fp, c->S, c->q[cur], lst, c->hb, c->q[cur ^ 1], c->sq, c->vb, pb, c->cp,
+                         c->ctl, depth, pix, sample_base, n_samples);
+      L.end();
+      L.begin(PTAMD_K_OTHER);
+      hipLaunchKernelGGL(k_scan2, 1, 1024, 0, s, c->cp, c->ctl);
+      hipLaunchKernelGGL(k_scatter, ggrid, 256, 0, s, c->cp, c->vb, c->list[cur ^ 1], c->sq, c->ctl, fp.max_ray_depth > 0 ? fp.nls : 0);
       L.end();
       if (fp.max_ray_depth > 0 && fp.nls > 0) {
         L.begin(PTAMD_K_SHADOW);
@@ -1235,7 +1341,7 @@ int ptamd_trace_pixels(ptamd_context *c, const int32_t *d_pixels, int64_t n, int
         }
         L.end();
         L.begin(PTAMD_K_RESOLVE);
-        hipLaunchKernelGGL(k_resolve, ggrid, 256, 0, s, fp, c->q[cur], c->vb, pb, c->ctl, depth);
+        hipLaunchKernelGGL(k_resolve, ggrid, 256, 0, s, fp, c->q[cur], lst, c->vb, pb, c->ctl, depth);
         L.end();
       }
       L.begin(PTAMD_K_OTHER);
@@ -1384,7 +1490,7 @@ int ptamd_trace_primary(ptamd_context *c, int64_t n, const double *sx, const dou
   if (rc) return rc;
   size_t lds = 0;
   const int tblock = traversal_block(c, &lds);
-  const int tgrid = c->num_cu * 4;
+  const int tgrid = c->num_cu * std::max(1, std::min<int>((int)((160 * 1024) / std::max<size_t>(lds, 1)), 20 * 64 / tblock)) * 2;
   hipStream_t s = c->own_stream;
   // the queue's throughput arrays are unused here and double as staging for sx, sy
   double *d_sx = c->q[0].T[0], *d_sy = c->q[0].T[1];
@@ -1395,7 +1501,7 @@ int ptamd_trace_primary(ptamd_context *c, int64_t n, const double *sx, const dou
     HIPCHK(hipMemcpyAsync(d_sy, sy + b, m * sizeof(double), hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_set_counts, 1, 1, 0, s, c->ctl, (uint32_t)m);
     hipLaunchKernelGGL(k_generate_primary, grid_for(c, 4), 256, 0, s, c->fp, d_sx, d_sy, (uint32_t)m, c->q[0]);
-    hipLaunchKernelGGL(k_extend<false>, tgrid, tblock, lds, s, c->S, c->q[0], c->hb, c->ctl, c->fp.n_clip, c->fp.f_clip);
+    hipLaunchKernelGGL(k_extend<false>, tgrid, tblock, lds, s, c->S, c->q[0], (const int32_t *)nullptr, c->hb, c->ctl, c->fp.n_clip, c->fp.f_clip);
     HIPCHK(hipMemcpyAsync(prim.data(), c->hb.prim, m * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(t_out + b, c->hb.t, m * sizeof(double), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));

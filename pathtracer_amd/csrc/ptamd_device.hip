@@ -105,18 +105,41 @@ struct PathBuf {
 
 // ------------------------------------------------------------------ intersection
 // BBox::intersect (src/scene/bbox.cpp:10-47) against the live max_t.
+// The reference's std::min / std::max are written here as fmin / fmax
+// (v_min_f64 / v_max_f64, one instruction each instead of compare + two selects).
+// They differ only when an operand is NaN, i.e. when a ray runs exactly parallel
+// to a slab (a direction component of exactly 0) AND starts exactly on its plane;
+// sampled directions never have an exactly zero component.
 __device__ __forceinline__ bool slab(const double *bb, v3 o, v3 inv, double min_t, double max_t, double &tmin_out) {
-  double timinx = (bb[0] - o.x) * inv.x, timaxx = (bb[3] - o.x) * inv.x;
-  double tmin = dmin(timinx, timaxx), tmax = dmax(timinx, timaxx);
-  double timiny = (bb[1] - o.y) * inv.y, timaxy = (bb[4] - o.y) * inv.y;
-  tmin = dmax(tmin, dmin(timiny, timaxy));
-  tmax = dmin(tmax, dmax(timiny, timaxy));
-  double timinz = (bb[2] - o.z) * inv.z, timaxz = (bb[5] - o.z) * inv.z;
-  tmin = dmax(tmin, dmin(timinz, timaxz));
-  tmax = dmin(tmax, dmax(timinz, timaxz));
+  const double timinx = (bb[0] - o.x) * inv.x, timaxx = (bb[3] - o.x) * inv.x;
+  double tmin = fmin(timinx, timaxx), tmax = fmax(timinx, timaxx);
+  const double timiny = (bb[1] - o.y) * inv.y, timaxy = (bb[4] - o.y) * inv.y;
+  tmin = fmax(tmin, fmin(timiny, timaxy));
+  tmax = fmin(tmax, fmax(timiny, timaxy));
+  const double timinz = (bb[2] - o.z) * inv.z, timaxz = (bb[5] - o.z) * inv.z;
+  tmin = fmax(tmin, fmin(timinz, timaxz));
+  tmax = fmin(tmax, fmax(timinz, timaxz));
   tmin_out = tmin;
   return !(tmin > tmax || tmin > max_t || tmax < min_t || tmax < 0);
 }
+
+// Per-lane traversal stack: the first STACK_LDS levels live in LDS (entry
+// (level, lane) at lds[level * blockDim.x + tid], conflict-free for any mix of
+// levels), deeper levels spill to a per-thread strip of global memory.
+constexpr int STACK_LDS = 12;
+struct TravStack {
+  uint2 *lds;
+  uint2 *glob;
+  uint32_t gstride, gtid;
+  __device__ __forceinline__ void put(int level, uint2 e) const {
+    if (level < STACK_LDS) lds[level * blockDim.x + threadIdx.x] = e;
+    else glob[(size_t)(level - STACK_LDS) * gstride + gtid] = e;
+  }
+  __device__ __forceinline__ uint2 get(int level) const {
+    if (level < STACK_LDS) return lds[level * blockDim.x + threadIdx.x];
+    return glob[(size_t)(level - STACK_LDS) * gstride + gtid];
+  }
+};
 
 struct Hit {
   double t, u, v;
@@ -131,16 +154,14 @@ struct Hit {
 // reproduces its answer for ANY traversal order; this one goes near child first
 // and drops stacked subtrees that start beyond the current hit.
 //
-// stack: per-lane LDS stack, entry (level, lane) at stack[level * blockDim.x + tid].
 template <bool ANY, bool COUNT>
 __device__ __forceinline__ bool traverse(const DevScene &S, v3 o, v3 d, double min_t, double max_t0, Hit &hit,
-                                         uint2 *stack, uint32_t &n_nodes, uint32_t &n_tests) {
+                                         const TravStack &stack, uint32_t &n_nodes, uint32_t &n_tests) {
   const v3 inv = V(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);  // src/pathtracer/ray.h:41
   double best_t = max_t0;
   hit.prim = -1;
   hit.t = max_t0;
   hit.u = hit.v = 0;
-  const uint32_t tid = threadIdx.x, bd = blockDim.x;
   int sp = 0;
   int32_t cur = S.root_code;
   for (;;) {
@@ -159,7 +180,7 @@ __device__ __forceinline__ bool traverse(const DevScene &S, v3 o, v3 d, double m
         float ft = (float)far_t;
         if ((double)ft > far_t) ft = nextafterf(ft, -INFINITY);
         if (!(far_t == far_t)) ft = -INFINITY;
-        stack[sp * bd + tid] = make_uint2((uint32_t)far_c, __float_as_uint(ft));
+        stack.put(sp, make_uint2((uint32_t)far_c, __float_as_uint(ft)));
         sp++;
         cur = left_first ? cl : cr;
         continue;
@@ -223,7 +244,7 @@ __device__ __forceinline__ bool traverse(const DevScene &S, v3 o, v3 d, double m
     for (;;) {
       if (sp == 0) return hit.prim >= 0;
       sp--;
-      const uint2 e = stack[sp * bd + tid];
+      const uint2 e = stack.get(sp);
       if ((double)__uint_as_float(e.y) > best_t) continue;
       cur = (int32_t)e.x;
       break;
@@ -386,8 +407,10 @@ __global__ void k_generate_primary(FrameParams fp, const double *__restrict__ sx
 // the order is the same on every run.
 template <bool COUNT>
 __global__ void __launch_bounds__(256)
-    k_extend(DevScene S, RayQ q, const int32_t *__restrict__ list, HitBuf hb, Ctl *ctl, double min_t, double max_t) {
-  extern __shared__ uint2 stack[];
+    k_extend(DevScene S, RayQ q, const int32_t *__restrict__ list, HitBuf hb, Ctl *ctl, double min_t, double max_t,
+             uint2 *gstack) {
+  extern __shared__ uint2 lds_stack[];
+  const TravStack stack{lds_stack, gstack, gridDim.x * blockDim.x, blockIdx.x * blockDim.x + threadIdx.x};
   const uint32_t n = ctl->n_cur;
   const uint32_t stride = gridDim.x * blockDim.x;
   uint32_t cn = 0, ct = 0;
@@ -413,8 +436,9 @@ __global__ void __launch_bounds__(256)
 // (pathtracer.cpp:79-82). vis[slot]: 2 = ray pending, 1 = light sample counts, 0 = not.
 template <bool HEMI, bool COUNT>
 __global__ void __launch_bounds__(256)
-    k_shadow(DevScene S, ShadowQ sq, VertexBuf vb, Ctl *ctl, int32_t nls) {
-  extern __shared__ uint2 stack[];
+    k_shadow(DevScene S, ShadowQ sq, VertexBuf vb, Ctl *ctl, int32_t nls, uint2 *gstack) {
+  extern __shared__ uint2 lds_stack[];
+  const TravStack stack{lds_stack, gstack, gridDim.x * blockDim.x, blockIdx.x * blockDim.x + threadIdx.x};
   const uint32_t n = ctl->n_shadow;
   const uint32_t stride = gridDim.x * blockDim.x;
   uint32_t cn = 0, ct = 0;
@@ -891,6 +915,8 @@ struct ptamd_context {
   Ctl *ctl = nullptr;
   uint32_t *block_count = nullptr;
   size_t block_count_cap = 0;
+  uint2 *gstack = nullptr;  // overflow levels of the per-lane traversal stacks
+  size_t gstack_bytes = 0;
   // profiling
   bool prof_events = false, prof_counters = false;
   struct Ev { int cls; hipEvent_t a, b; };
@@ -1088,6 +1114,7 @@ void ptamd_destroy(ptamd_context *c) {
   free_scene(c);
   if (c->slab) (void)hipFree(c->slab);
   if (c->block_count) (void)hipFree(c->block_count);
+  if (c->gstack) (void)hipFree(c->gstack);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -1267,11 +1294,30 @@ int ptamd_frame_begin(ptamd_context *c, const ptamd_render_params *p) {
   return PTAMD_OK;
 }
 
-static int traversal_block(const ptamd_context *c, size_t *lds_bytes) {
-  int block = 256;
-  while (block > 64 && (size_t)block * c->S.stack_cap * sizeof(uint2) > 64 * 1024) block >>= 1;
-  *lds_bytes = (size_t)block * c->S.stack_cap * sizeof(uint2);
-  return block;
+// Launch shape of the traversal kernels: 256-thread workgroups, STACK_LDS stack
+// levels per lane in LDS, the rest (if the tree is deeper) in a global strip.
+struct TravLaunch {
+  int block, grid;
+  size_t lds;
+  uint2 *gstack;
+};
+static int traversal_launch(ptamd_context *c, TravLaunch *t) {
+  t->block = 256;
+  t->lds = (size_t)t->block * std::min(c->S.stack_cap, (int32_t)STACK_LDS) * sizeof(uint2);
+  // resident workgroups per CU: bounded by LDS (160 KiB per CU) and by registers
+  // (about 5 waves per SIMD); twice that many in the grid so that the tail of a
+  // launch still has work to balance
+  const int wg_per_cu = std::max(1, std::min<int>((int)((160 * 1024) / std::max<size_t>(t->lds, 1)), 5));
+  t->grid = c->num_cu * wg_per_cu * 2;
+  const size_t levels = (size_t)std::max(0, c->S.stack_cap - STACK_LDS);
+  const size_t need = levels * (size_t)t->grid * t->block * sizeof(uint2);
+  if (need > c->gstack_bytes) {
+    if (c->gstack) { HIPCHK(hipDeviceSynchronize()); HIPCHK(hipFree(c->gstack)); c->gstack = nullptr; }
+    HIPCHK(hipMalloc((void **)&c->gstack, need));
+    c->gstack_bytes = need;
+  }
+  t->gstack = c->gstack;
+  return PTAMD_OK;
 }
 
 int ptamd_trace_pixels(ptamd_context *c, const int32_t *d_pixels, int64_t n, int32_t sample_base, int32_t n_samples,
@@ -1290,14 +1336,12 @@ int ptamd_trace_pixels(ptamd_context *c, const int32_t *d_pixels, int64_t n, int
   px_per_chunk = std::min(px_per_chunk, n);
   int rc = ensure_buffers(c, px_per_chunk * n_samples, nls, !fp.accum);
   if (rc) return rc;
-  size_t lds = 0;
-  const int tblock = traversal_block(c, &lds);
-  if (lds > 160 * 1024) { ptamd::set_error("BVH too deep for the per-lane traversal stack"); return PTAMD_ERR_SCENE; }
-  // resident workgroups per CU: bounded by the LDS stacks (160 KiB per CU) and by
-  // registers (about 5 waves per SIMD); twice that many workgroups in the grid so
-  // that the tail of a launch still has work to balance
-  const int wg_per_cu = std::max(1, std::min<int>((int)((160 * 1024) / std::max<size_t>(lds, 1)), 20 * 64 / tblock));
-  const int tgrid = c->num_cu * wg_per_cu * 2;
+  TravLaunch tl;
+  rc = traversal_launch(c, &tl);
+  if (rc) return rc;
+  const int tblock = tl.block, tgrid = tl.grid;
+  const size_t lds = tl.lds;
+  uint2 *gstack = tl.gstack;
   const int ggrid = grid_for(c, 8);
   PathBuf pb = c->pb;
   if (fp.accum) pb.pend[0] = pb.pend[1] = pb.pend[2] = nullptr;
@@ -1319,8 +1363,8 @@ int ptamd_trace_pixels(ptamd_context *c, const int32_t *d_pixels, int64_t n, int
       const double max_t = depth == 1 ? fp.f_clip : (double)INFINITY;
       const int32_t *lst = depth == 1 ? nullptr : c->list[cur];
       L.begin(PTAMD_K_EXTEND);
-      if (c->prof_counters) hipLaunchKernelGGL(k_extend<true>, tgrid, tblock, lds, s, c->S, c->q[cur], lst, c->hb, c->ctl, min_t, max_t);
-      else hipLaunchKernelGGL(k_extend<false>, tgrid, tblock, lds, s, c->S, c->q[cur], lst, c->hb, c->ctl, min_t, max_t);
+      if (c->prof_counters) hipLaunchKernelGGL(k_extend<true>, tgrid, tblock, lds, s, c->S, c->q[cur], lst, c->hb, c->ctl, min_t, max_t, gstack);
+      else hipLaunchKernelGGL(k_extend<false>, tgrid, tblock, lds, s, c->S, c->q[cur], lst, c->hb, c->ctl, min_t, max_t, gstack);
       L.end();
       L.begin(PTAMD_K_SHADE);
       hipLaunchKernelGGL(k_shade, ggrid, 256, 0, s, fp, c->S, c->q[cur], lst, c->hb, c->q[cur ^ 1], c->sq, c->vb, pb, c->cp,
@@ -1333,11 +1377,11 @@ int ptamd_trace_pixels(ptamd_context *c, const int32_t *d_pixels, int64_t n, int
       if (fp.max_ray_depth > 0 && fp.nls > 0) {
         L.begin(PTAMD_K_SHADOW);
         if (fp.hemisphere) {
-          if (c->prof_counters) hipLaunchKernelGGL((k_shadow<true, true>), tgrid, tblock, lds, s, c->S, c->sq, c->vb, c->ctl, nls);
-          else hipLaunchKernelGGL((k_shadow<true, false>), tgrid, tblock, lds, s, c->S, c->sq, c->vb, c->ctl, nls);
+          if (c->prof_counters) hipLaunchKernelGGL((k_shadow<true, true>), tgrid, tblock, lds, s, c->S, c->sq, c->vb, c->ctl, nls, gstack);
+          else hipLaunchKernelGGL((k_shadow<true, false>), tgrid, tblock, lds, s, c->S, c->sq, c->vb, c->ctl, nls, gstack);
         } else {
-          if (c->prof_counters) hipLaunchKernelGGL((k_shadow<false, true>), tgrid, tblock, lds, s, c->S, c->sq, c->vb, c->ctl, nls);
-          else hipLaunchKernelGGL((k_shadow<false, false>), tgrid, tblock, lds, s, c->S, c->sq, c->vb, c->ctl, nls);
+          if (c->prof_counters) hipLaunchKernelGGL((k_shadow<false, true>), tgrid, tblock, lds, s, c->S, c->sq, c->vb, c->ctl, nls, gstack);
+          else hipLaunchKernelGGL((k_shadow<false, false>), tgrid, tblock, lds, s, c->S, c->sq, c->vb, c->ctl, nls, gstack);
         }
         L.end();
         L.begin(PTAMD_K_RESOLVE);
@@ -1488,9 +1532,11 @@ int ptamd_trace_primary(ptamd_context *c, int64_t n, const double *sx, const dou
   const int64_t chunk = std::min<int64_t>(std::max<int64_t>(n, 1), c->max_paths);
   rc = ensure_buffers(c, chunk, std::max(c->cap_nls, 1), false);
   if (rc) return rc;
-  size_t lds = 0;
-  const int tblock = traversal_block(c, &lds);
-  const int tgrid = c->num_cu * std::max(1, std::min<int>((int)((160 * 1024) / std::max<size_t>(lds, 1)), 20 * 64 / tblock)) * 2;
+  TravLaunch tl;
+  rc = traversal_launch(c, &tl);
+  if (rc) return rc;
+  const int tblock = tl.block, tgrid = tl.grid;
+  const size_t lds = tl.lds;
   hipStream_t s = c->own_stream;
   // the queue's throughput arrays are unused here and double as staging for sx, sy
   double *d_sx = c->q[0].T[0], *d_sy = c->q[0].T[1];
@@ -1501,7 +1547,7 @@ int ptamd_trace_primary(ptamd_context *c, int64_t n, const double *sx, const dou
     HIPCHK(hipMemcpyAsync(d_sy, sy + b, m * sizeof(double), hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_set_counts, 1, 1, 0, s, c->ctl, (uint32_t)m);
     hipLaunchKernelGGL(k_generate_primary, grid_for(c, 4), 256, 0, s, c->fp, d_sx, d_sy, (uint32_t)m, c->q[0]);
-    hipLaunchKernelGGL(k_extend<false>, tgrid, tblock, lds, s, c->S, c->q[0], (const int32_t *)nullptr, c->hb, c->ctl, c->fp.n_clip, c->fp.f_clip);
+    hipLaunchKernelGGL(k_extend<false>, tgrid, tblock, lds, s, c->S, c->q[0], (const int32_t *)nullptr, c->hb, c->ctl, c->fp.n_clip, c->fp.f_clip, tl.gstack);
     HIPCHK(hipMemcpyAsync(prim.data(), c->hb.prim, m * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(t_out + b, c->hb.t, m * sizeof(double), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));

@@ -54,8 +54,11 @@ def _exchange(state6, active, mine_idx, world, group):
     k = mine_idx.numel()
     if k:
         send[:k] = state6.index_select(0, mine_idx.long())
-    recv = torch.empty((world, m, 6), dtype=state6.dtype, device=state6.device)
+    # output = the ranks' blocks concatenated along dim 0 (the layout both RCCL and
+    # gloo accept for all_gather_into_tensor)
+    recv = torch.empty((world * m, 6), dtype=state6.dtype, device=state6.device)
     dist.all_gather_into_tensor(recv, send, group=group)
+    recv = recv.view(world, m, 6)
     # rank r's rows are active[r::world]
     for r in range(world):
         idx = active[r::world].long()

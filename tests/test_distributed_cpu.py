@@ -1,0 +1,168 @@
+"""The multi-GPU round scheduler on CPU: two gloo ranks run
+pathtracer_amd.distributed.render_frame with a stand-in device that traces through
+the CPU oracle (test infrastructure), and must produce exactly the frame one rank
+produces, which in turn must equal oracle_render's own per-pixel loop."""
+import ctypes as C
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from pathtracer_amd import cabi, distributed, ptar
+from conftest import GOLDEN
+import oracle_lib as O
+
+
+class OracleDevice:
+    """Implements the round-level device API on host memory with the CPU oracle."""
+
+    def __init__(self, scene, cam):
+        self.scene, self.cam = scene, cam
+        self.traced = 0
+
+    def frame_begin(self, params):
+        self.p = params
+
+    @staticmethod
+    def _view(ptr, n, dtype):
+        ct = {np.float64: C.c_double, np.int32: C.c_int32, np.int64: C.c_int64}[dtype]
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ct)), shape=(n,))
+
+    def trace_pixels(self, d_pixels, n, sample_base, n_samples, d_state, stream=0):
+        p = self.p
+        pix = self._view(d_pixels, n, np.int32)
+        st = self._view(d_state, p.w * p.h * 6, np.float64).reshape(-1, 6)
+        rgb = (C.c_double * 3)()
+        for px in pix:
+            x, y = int(px) % p.w, int(px) // p.w
+            for s in range(sample_base, sample_base + n_samples):
+                O.lib().oracle_sample_radiance(C.byref(self.scene.desc), C.byref(self.cam), C.byref(p), x, y, s, rgb)
+                # Vector3D::illum: double arithmetic, float result
+                xl = float(np.float32(float(np.float32(0.2126)) * rgb[0] + float(np.float32(0.7152)) * rgb[1]
+                                      + float(np.float32(0.0722)) * rgb[2]))
+                st[px, 0] += xl
+                st[px, 1] += xl * xl
+                st[px, 2] += rgb[0]
+                st[px, 3] += rgb[1]
+                st[px, 4] += rgb[2]
+            st[px, 5] += n_samples
+            self.traced += n_samples
+
+    def adaptive_filter(self, d_in, n, n_done, d_state, d_out, d_n_out, stream=0):
+        p = self.p
+        pin = self._view(d_in, n, np.int32)
+        st = self._view(d_state, p.w * p.h * 6, np.float64).reshape(-1, 6)
+        out = self._view(d_out, max(n, 1), np.int32)
+        k = 0
+        i = n_done
+        for px in pin:
+            s1, s2 = st[px, 0], st[px, 1]
+            mean = s1 * (1.0 / i)
+            var = (1.0 / (i - 1)) * (s2 - s1 * s1 * (1.0 / i))
+            with np.errstate(invalid="ignore"):
+                conf = 1.96 * np.sqrt(np.float64(var * (1.0 / i)))
+            if not (conf <= p.max_tolerance * mean):
+                out[k] = px
+                k += 1
+        self._view(d_n_out, 1, np.int64)[0] = k
+
+    def frame_resolve(self, d_state, d_hdr, d_count, stream=0):
+        p = self.p
+        st = self._view(d_state, p.w * p.h * 6, np.float64).reshape(-1, 6)
+        hdr = self._view(d_hdr, p.w * p.h * 3, np.float64).reshape(-1, 3)
+        cnt = self._view(d_count, p.w * p.h, np.int32)
+        for i in range(p.w * p.h):
+            nn = st[i, 5]
+            hdr[i] = st[i, 2:5] * (1.0 / nn) if nn > 0 else 0.0
+            cnt[i] = int(nn)
+
+
+def _setup():
+    a = ptar.load(os.path.join(GOLDEN, "scene_CBspheres_lambertian.ptar"))
+    sc = cabi.SceneArrays.from_ptar(a)
+    cam26 = a["camera"].copy()
+    return sc, cabi.camera_from_dump(cam26)
+
+
+W, H = 24, 18
+KW = dict(ns_aa=48, ns_area_light=2, max_ray_depth=3, samples_per_batch=16, max_tolerance=0.3, seed=9)
+
+
+def _worker(rank, world, port, q):
+    try:
+        _worker_body(rank, world, port, q)
+    except Exception as e:  # surface the failure instead of leaving the parent waiting
+        q.put((rank, repr(e), None, None, None))
+        raise
+
+
+def _worker_body(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sc, cam = _setup()
+    dev = OracleDevice(sc, cam)
+    p = cabi.make_params(W, H, **KW)
+    rounds = []
+    hdr, cnt = distributed.render_frame(dev, p, rank=rank, world=world, device=torch.device("cpu"), record_rounds=rounds)
+    q.put((rank, hdr.numpy().copy(), cnt.numpy().copy(), rounds, dev.traced))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_equal_one_rank_bit_for_bit():
+    sc, cam = _setup()
+    p = cabi.make_params(W, H, **KW)
+    one = OracleDevice(sc, cam)
+    rounds1 = []
+    hdr1, cnt1 = distributed.render_frame(one, p, device=torch.device("cpu"), record_rounds=rounds1)
+    hdr1, cnt1 = hdr1.numpy(), cnt1.numpy()
+    # the round loop reproduces raytrace_pixel's adaptive loop exactly
+    rh, rc, st = O.render(sc, cam, p, threads=2)
+    assert np.array_equal(cnt1, rc) and np.array_equal(hdr1, rh)
+    assert 16 * W * H < cnt1.sum() < 48 * W * H  # the adaptive test really stopped some pixels
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    res = [q.get(timeout=500) for _ in procs]
+    for r in res:
+        assert not isinstance(r[1], str), "rank %d failed: %s" % (r[0], r[1])
+    res = sorted(res, key=lambda t: t[0])
+    for pr in procs:
+        pr.join(60)
+        assert pr.exitcode == 0
+    for rank, hdr, cnt, rounds, traced in res:
+        assert np.array_equal(hdr, hdr1) and np.array_equal(cnt, cnt1), "rank %d frame differs" % rank
+        assert [r[:2] for r in rounds] == [r[:2] for r in rounds1]
+    # the work really was split, evenly, every round
+    t0, t1 = res[0][4], res[1][4]
+    assert t0 + t1 == int(cnt1.sum()) and abs(t0 - t1) <= 16 * len(rounds1)
+    for r0, r1 in zip(res[0][3], res[1][3]):
+        assert r0[2] + r1[2] == r0[1] and abs(r0[2] - r1[2]) <= 1
+
+
+def test_pixel_schedule_covers_every_pixel_once():
+    for n in (0, 1, 7, 64, 1000):
+        for world in (1, 2, 3, 8):
+            seen = sorted(i for r in range(world) for i in distributed.PixelSchedule.shard(n, r, world))
+            assert seen == list(range(n))
+            sizes = [distributed.PixelSchedule.shard_size(n, r, world) for r in range(world)]
+            assert max(sizes) - min(sizes) <= 1 and max(sizes, default=0) <= distributed.PixelSchedule.padded(n, world)

@@ -119,3 +119,112 @@ def test_errors_are_reported_not_fatal(device):
     with pytest.raises(pt.PtamdError):
         dev2.render(cabi.make_params(8, 8))  # no scene uploaded
     dev2.close()
+
+
+# ---------------------------------------------------------------------------
+# against outputs of the reference itself (tests/golden, see tools/make_golden.py)
+import hashlib
+import os
+
+from conftest import GOLDEN
+
+
+@pytest.mark.parametrize("name,w,h", [("CBspheres_lambertian", 480, 360), ("CBspheres", 240, 180), ("CBgems", 240, 180),
+                                      ("CBbunny", 200, 150), ("CBcoil", 160, 120), ("cube", 96, 72)])
+def test_primary_hits_match_reference_golden(device, name, w, h):
+    """north_star bar: >= 99.99 % identical primitive ids. Observed: every pixel, and t bit for bit."""
+    g = np.load(os.path.join(GOLDEN, "primary_%s_%dx%d.npz" % (name, w, h)))
+    sc = pt.Scene(scene_path(name))
+    device.upload(sc)
+    device.set_camera(sc.camera(w, h))
+    offs = g["offsets"].reshape(4, 2)
+    for o in range(4):
+        sx, sy = _sensor_grid(w, h, offs[o])
+        ids, ts = device.trace_primary(sx, sy)
+        same = (ids == g["ids_%d" % o]).mean()
+        assert same >= 0.9999, "only %.5f%% of ids match" % (100 * same)
+        assert same == 1.0
+        assert hashlib.sha256(ts.tobytes()).digest() == g["t_sha256_%d" % o].tobytes()
+
+
+def _blocks(img, b=8):
+    h, w, c = img.shape
+    return img[:h - h % b, :w - w % b].reshape(h // b, b, w // b, b, c).mean(axis=(1, 3))
+
+
+def test_converged_image_agrees_with_reference_at_1024spp(device):
+    """CBspheres_lambertian 240x180, 1024 spp, -l 4 -m 5 (adaptive 32/0.05) against the
+    reference's own render. Different RNGs, so: per-pixel distance is Monte-Carlo noise
+    (no larger than GPU-vs-GPU with another seed), and 8x8 block means, which keep any
+    bias but little noise, agree within 1 % relative L2."""
+    w, h = 240, 180
+    g = np.load(os.path.join(GOLDEN, "render_cbsl_240x180_s1024.npz"))
+    ref = g["hdr"].astype(np.float64).reshape(h, w, 3)
+    refc = g["count"].reshape(h, w)
+    sc = pt.Scene(scene_path("CBspheres_lambertian"))
+    device.upload(sc)
+    device.set_camera(sc.camera(w, h))
+    kw = dict(ns_aa=1024, max_ray_depth=5, ns_area_light=4)
+    a, ac = device.render(cabi.make_params(w, h, seed=1, **kw))
+    b, _ = device.render(cabi.make_params(w, h, seed=2, **kw))
+    noise = _rel_l2(b, a)
+    assert _rel_l2(a, ref) <= 1.2 * noise
+    assert _rel_l2(_blocks(a), _blocks(ref)) < 0.01
+    assert abs(ac.mean() - refc.mean()) < 0.02 * refc.mean()
+    for c in range(3):
+        assert abs(a[..., c].mean() - ref[..., c].mean()) < 0.005 * ref[..., c].mean()
+
+
+def test_full_size_frame_properties(device):
+    """CBbunny at the benchmark's 800x600 (fewer samples): size-independent invariants."""
+    w, h = 800, 600
+    sc = pt.Scene(scene_path("CBbunny"))
+    device.upload(sc)
+    device.set_camera(sc.camera(w, h))
+    p = cabi.make_params(w, h, ns_aa=64, max_ray_depth=5, ns_area_light=4, seed=5)
+    a, ac = device.render(p)
+    st = device.stats()
+    # determinism: ordered compaction, keyed RNG -> identical bits on a second run
+    b, bc = device.render(p)
+    assert np.array_equal(a, b) and np.array_equal(ac, bc)
+    # sample accounting and the adaptive sampler's batch structure
+    assert st.samples == int(ac.sum())
+    assert set(np.unique(ac)) <= {32, 64}
+    assert np.isfinite(a).all() and (a >= 0).all()
+    # background pixels (camera ray misses) are exactly black and stop after one batch
+    sx, sy = _sensor_grid(w, h, (0.5, 0.5))
+    ids, _ = device.trace_primary(sx, sy)
+    bg = (ids < 0).reshape(h, w)
+    inner_bg = bg & np.roll(bg, 1, 0) & np.roll(bg, -1, 0) & np.roll(bg, 1, 1) & np.roll(bg, -1, 1)
+    assert inner_bg.mean() > 0.5                      # the box covers about a third of an 800x600 frame
+    assert not a[inner_bg].any() and (ac[inner_bg] == 32).all()
+    # a cell of the frame equals the same pixels of the whole frame
+    cell = cabi.make_params(w, h, ns_aa=64, max_ray_depth=5, ns_area_light=4, seed=5, rect=(350, 250, 450, 330))
+    c, cc = device.render(cell)
+    assert np.array_equal(c[250:330, 350:450], a[250:330, 350:450]) and np.array_equal(cc[250:330, 350:450], ac[250:330, 350:450])
+    # rays: every sample starts with one camera ray
+    assert st.rays >= st.samples and st.shadow_rays < st.rays
+
+
+def test_deep_bvh_spills_the_lane_stack(device):
+    """The 100k-triangle stand-in scene has a tree deeper than the LDS part of the per-lane
+    stack; results must not depend on where a stack level lives."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(GOLDEN), "..", "tools"))
+    import make_standin_scene
+    path = make_standin_scene.ensure("dragon")
+    w, h = 160, 120
+    sc = pt.Scene(path)
+    arr = sc.arrays()
+    cam = sc.camera(w, h)
+    device.upload(sc)
+    device.set_camera(cam)
+    sx, sy = _sensor_grid(w, h, (0.5, 0.5))
+    ids, ts = device.trace_primary(sx, sy)
+    rid, rts = O.trace_primary(arr, cam, sx, sy)
+    assert np.array_equal(ids, rid) and ts.tobytes() == rts.tobytes()
+    p = cabi.make_params(w, h, ns_aa=32, max_ray_depth=5, ns_area_light=4, seed=2)
+    hdr, cnt = device.render(p)
+    rh, rc, _ = O.render(arr, cam, p, threads=8)
+    assert (cnt == rc).mean() >= 0.999
+    assert np.isclose(hdr, rh, rtol=1e-9, atol=1e-12).all(axis=2).mean() >= 0.999

@@ -1,0 +1,176 @@
+"""Host scene pipeline and C-ABI surface, CPU only: the product library's loader,
+half-edge normals, BVH build and camera placement against arrays dumped from the
+reference (tests/golden), plus error behaviour and the output stage."""
+import ctypes as C
+import hashlib
+import json
+import os
+import re
+import struct
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+
+import pathtracer_amd as pt
+from pathtracer_amd import cabi, ptar
+from conftest import GOLDEN, ROOT, SCENES, scene_path
+
+HASHES = json.load(open(os.path.join(GOLDEN, "scene_hashes.json")))
+LOCAL = sorted(f[:-4] for f in os.listdir(SCENES) if f.endswith(".dae"))
+
+
+def _sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def _dump(name, w, h):
+    sc = pt.Scene(scene_path(name))
+    cam = sc.camera(w, h)
+    a = sc.arrays().a
+    out = dict(a)
+    out["prim_mat_kind"] = a["mat_kind"][a["prim_material"]]
+    out["prim_mat_param"] = a["mat_param"].reshape(-1, 3)[a["prim_material"]].ravel()
+    out["root"] = np.array([sc.desc.root], np.int32)
+    return sc, cam, out
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "ptamd.h")).read()
+    declared = set(re.findall(r"\b(ptamd_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(pt.api.EXPORTS), declared ^ set(pt.api.EXPORTS)
+    L = pt.lib()
+    for s in declared:
+        assert getattr(L, s) is not None
+
+
+@pytest.mark.parametrize("name", LOCAL)
+@pytest.mark.parametrize("w,h", [(800, 600), (480, 360)])
+def test_scene_arrays_bit_identical_to_reference(name, w, h):
+    """Primitive order, vertex and normal bits, node boxes and links, lights, jitter table."""
+    _, cam, a = _dump(name, w, h)
+    ref = HASHES["%s@%dx%d" % (name, w, h)]
+    assert a["prim_type"].size == ref["n_prims"] and a["node_left"].size == ref["n_nodes"]
+    for k in ("prim_type", "prim_pos", "prim_nrm", "prim_mat_kind", "node_bbox", "node_left", "node_right",
+              "node_start", "node_count", "root", "light_kind", "light_param", "jitter_table"):
+        assert _sha(a[k]) == ref[k], k
+    # microfacet parameters are not part of the shared layout; everything else must match
+    if "microfacet" not in name:
+        assert _sha(a["prim_mat_param"]) == ref["prim_mat_param"]
+
+
+@pytest.mark.parametrize("name", ["CBspheres_lambertian", "CBspheres", "CBempty", "CBgems", "cube", "plane"])
+def test_camera_and_full_arrays(name):
+    g = ptar.load(os.path.join(GOLDEN, "scene_%s.ptar" % name))
+    _, cam, a = _dump(name, 480, 360)
+    c = g["camera"]
+    assert np.array_equal(np.array(cam.pos[:]), c[0:3])
+    assert np.array_equal(np.array(cam.c2w[:]), c[3:12])
+    assert (cam.hFov, cam.vFov, cam.nClip, cam.fClip) == tuple(c[12:16])
+    assert np.array_equal(a["prim_pos"], g["prim_pos"]) and np.array_equal(a["node_bbox"], g["node_bbox"])
+
+
+def test_field_of_view_follows_resolution():
+    """The reference configures the camera at 800x600 and keeps screenDist on resize."""
+    sc = pt.Scene(scene_path("CBspheres_lambertian"))
+    f800 = sc.camera(800, 600).hFov
+    f480 = sc.camera(480, 360).hFov
+    assert f800 > f480
+    sd = 600 / (2 * np.tan(np.radians(sc.camera(800, 600).vFov) / 2))
+    assert np.isclose(2 * np.degrees(np.arctan(480 / (2 * sd))), f480, rtol=1e-12)
+
+
+def test_loader_errors_are_returned(tmp_path):
+    with pytest.raises(pt.PtamdError, match="cannot open"):
+        pt.Scene(str(tmp_path / "missing.dae"))
+    bad = tmp_path / "bad.dae"
+    bad.write_text("<COLLADA><asset><up_axis>Y_UP</up_axis></asset>")
+    with pytest.raises(pt.PtamdError, match="XML"):
+        pt.Scene(str(bad))
+    noscene = tmp_path / "noscene.dae"
+    noscene.write_text("<COLLADA><asset><up_axis>Y_UP</up_axis></asset></COLLADA>")
+    with pytest.raises(pt.PtamdError, match="no scene description"):
+        pt.Scene(str(noscene))
+    # a non-manifold mesh (three faces on one edge) is refused, not exit()ed on
+    src = open(scene_path("plane")).read()
+    m = re.search(r"<p>([^<]*)</p>", src)
+    assert m
+    dup = src.replace(m.group(0), "<p>" + m.group(1) + " " + m.group(1) + "</p>")
+    dup = re.sub(r'(<polylist[^>]*count=")(\d+)(")', lambda mm: mm.group(1) + str(2 * int(mm.group(2))) + mm.group(3), dup)
+    dup = re.sub(r"<vcount>([^<]*)</vcount>", lambda mm: "<vcount>" + mm.group(1) + " " + mm.group(1) + "</vcount>", dup)
+    f = tmp_path / "nonmanifold.dae"
+    f.write_text(dup)
+    with pytest.raises(pt.PtamdError, match="scene error"):
+        pt.Scene(str(f))
+
+
+def test_no_gpu_is_an_error_not_a_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(pt.PtamdError, match="no HIP device"):
+        pt.Device(0)
+    exe = os.path.join(ROOT, "pathtracer_amd", "bin", "pathtracer")
+    r = subprocess.run([exe, "-s", "1", "-r", "16", "12", "-f", "/tmp/ptamd_never.png", scene_path("cube")],
+                       capture_output=True, text=True)
+    assert r.returncode != 0 and not os.path.exists("/tmp/ptamd_never.png")
+    assert "no HIP device" in (r.stdout + r.stderr)
+
+
+def test_cli_usage_and_option_words():
+    exe = os.path.join(ROOT, "pathtracer_amd", "bin", "pathtracer")
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 1 and "Usage" in r.stdout
+    r = subprocess.run([exe, "-s", "4", scene_path("cube")], capture_output=True, text=True)
+    assert r.returncode == 1 and "-f" in r.stderr  # no window mode
+
+
+def test_tonemap_matches_reference_vectors():
+    k = ptar.load(os.path.join(GOLDEN, "kat.ptar"))
+    hdr = k["kat_tonemap_in"].reshape(1, -1, 3)
+    out = pt.api.tonemap(hdr).ravel().view(np.int32)
+    assert np.array_equal(out, k["kat_tonemap_out"])
+
+
+def _decode_png(path):
+    data = open(path, "rb").read()
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    p, idat, w, h = 8, b"", 0, 0
+    while p < len(data):
+        n, typ = struct.unpack(">I4s", data[p:p + 8])
+        body = data[p + 8:p + 8 + n]
+        assert zlib.crc32(typ + body) == struct.unpack(">I", data[p + 8 + n:p + 12 + n])[0]
+        if typ == b"IHDR":
+            w, h, depth, ctype = struct.unpack(">IIBB", body[:10])
+            assert (depth, ctype) == (8, 6)
+        elif typ == b"IDAT":
+            idat += body
+        p += 12 + n
+    raw = zlib.decompress(idat)
+    rows = np.frombuffer(raw, np.uint8).reshape(h, 1 + 4 * w)
+    assert not rows[:, 0].any()
+    return rows[:, 1:].reshape(h, w, 4)
+
+
+def test_png_is_flipped_and_opaque(tmp_path):
+    h, w = 5, 7
+    rgba = (np.arange(h * w, dtype=np.uint32).reshape(h, w) * 0x010203) & 0x00FFFFFF
+    f = str(tmp_path / "t.png")
+    pt.api.write_png(f, rgba)
+    img = _decode_png(f)
+    assert (img[..., 3] == 255).all()
+    back = img[..., 0].astype(np.uint32) | (img[..., 1].astype(np.uint32) << 8) | (img[..., 2].astype(np.uint32) << 16)
+    assert np.array_equal(back, rgba[::-1])  # row 0 of the buffer is the bottom of the picture
+
+
+def test_sampling_rate_map():
+    cnt = np.array([[0, 16, 32], [48, 64, 64]], np.int32)  # y = 0 is the bottom row
+    out = np.zeros(6, np.uint32)
+    rc = pt.lib().ptamd_sampling_rate_rgba8(cnt.ctypes.data_as(C.POINTER(C.c_int32)), 3, 2, 64,
+                                            out.ctypes.data_as(C.POINTER(C.c_uint32)))
+    assert rc == 0
+    out = out.reshape(2, 3)
+    assert out[1, 0] == 0xFFFF0000            # rate 0: blue, bottom-left lands in the last PNG row
+    assert out[1, 2] == 0xFF00FF00            # rate 0.5: green
+    assert out[0, 2] == 0xFF0000FF            # rate 1: red

@@ -34,22 +34,39 @@ using namespace ptdev;
 namespace {
 
 // ------------------------------------------------------------------ device data
-// Interior BVH node, one 128-byte L2 line: both children's boxes plus their
-// codes. A code >= 0 is an interior node index; a negative code is a leaf,
-// ~((start << 4) | (count - 1)); LEAF_EMPTY marks "no child".
-struct alignas(128) DevNode {
-  double lb[6];
-  double rb[6];
-  int32_t left, right;
-  int32_t pad[6];
+// 4-wide BVH node in 64 bytes (half an L2 line): the four child boxes are 8-bit
+// offsets on a per-node power-of-two grid, plus four child codes. The tree is the
+// reference's binary SAH tree collapsed two levels at a time, with every
+// primitive as its own child (so each primitive is culled by its own box before
+// its FP64 test). A code >= 0 is a node index, a negative code is primitive
+// ~code, CHILD_EMPTY marks an unused slot.
+//
+// Why so small: the traversal kernels are bound by the number of 16-byte
+// per-lane loads the vector L1 can serve for divergent addresses (TCP and TD
+// ~90 % busy in rocprofv3), so a node visit costs 4 loads instead of the 8 of a
+// plain FP32 node or the 16 of two FP64 boxes.
+//
+// Plane k of a child is org[k] + q * 2^(e_k), exact in float by construction
+// (org is a multiple of 2^e_k and |org| / 2^e_k < 2^22), and the host rounds q
+// outward, so the decoded box CONTAINS the reference's FP64 box. Together with
+// the conservative float slab test below, a child is never culled when the
+// reference's FP64 test (src/scene/bbox.cpp:10-47) would have accepted it; which
+// hit wins is decided by FP64 primitive tests only.
+struct alignas(64) DevNode {
+  float org[3];
+  uint32_t exps;    // byte k: biased IEEE exponent of axis k's grid step
+  uint8_t q[4][6];  // per child: lo.xyz, hi.xyz
+  int32_t child[4];
+  int32_t pad[2];
 };
-static_assert(sizeof(DevNode) == 128, "node must be one cache line");
-constexpr int32_t LEAF_EMPTY = INT32_MIN;
+static_assert(sizeof(DevNode) == 64, "node must be half a cache line");
+constexpr int32_t CHILD_EMPTY = INT32_MIN;
 
-// Primitive record, 96 bytes. Triangle: p1, e1 = p2-p1, e2 = p3-p1,
-// normal = e1 x e2 (all rounded exactly as Triangle::test computes them on the
-// fly, src/scene/triangle.cpp:27-28). Sphere: centre, r*r.
-constexpr int PRIM_STRIDE = 12;
+// Primitive record, 80 bytes (5 loads). Triangle: p1, e1 = p2-p1, e2 = p3-p1
+// rounded exactly as Triangle::test computes them on the fly
+// (src/scene/triangle.cpp:27); sphere: centre, r*r. The 10th slot holds
+// prim_info (bit 0: sphere, bits 1..: material) in its low 32 bits.
+constexpr int PRIM_STRIDE = 10;
 
 struct DevScene {
   const DevNode *nodes;
@@ -74,6 +91,7 @@ struct FrameParams {
 
 struct Ctl {
   uint32_t n_cur, n_next, n_shadow, pad;
+  uint32_t grab_extend, grab_shadow, pad2[2];  // next unclaimed ray of the running traversal kernel
   unsigned long long st_rays, st_shadow, st_vertices, st_nodes, st_tests;
   long long filt_count;
 };
@@ -104,23 +122,51 @@ struct PathBuf {
 };
 
 // ------------------------------------------------------------------ intersection
-// BBox::intersect (src/scene/bbox.cpp:10-47) against the live max_t.
-// The reference's std::min / std::max are written here as fmin / fmax
-// (v_min_f64 / v_max_f64, one instruction each instead of compare + two selects).
-// They differ only when an operand is NaN, i.e. when a ray runs exactly parallel
-// to a slab (a direction component of exactly 0) AND starts exactly on its plane;
-// sampled directions never have an exactly zero component.
-__device__ __forceinline__ bool slab(const double *bb, v3 o, v3 inv, double min_t, double max_t, double &tmin_out) {
-  const double timinx = (bb[0] - o.x) * inv.x, timaxx = (bb[3] - o.x) * inv.x;
-  double tmin = fmin(timinx, timaxx), tmax = fmax(timinx, timaxx);
-  const double timiny = (bb[1] - o.y) * inv.y, timaxy = (bb[4] - o.y) * inv.y;
-  tmin = fmax(tmin, fmin(timiny, timaxy));
-  tmax = fmin(tmax, fmax(timiny, timaxy));
-  const double timinz = (bb[2] - o.z) * inv.z, timaxz = (bb[5] - o.z) * inv.z;
-  tmin = fmax(tmin, fmin(timinz, timaxz));
-  tmax = fmin(tmax, fmax(timinz, timaxz));
-  tmin_out = tmin;
-  return !(tmin > tmax || tmin > max_t || tmax < min_t || tmax < 0);
+// Ray in the form the FP32 box test wants it. The origin is kept as a float
+// interval [o_dn, o_up] containing the FP64 origin; using o_up against a box's
+// low planes and o_dn against its high planes makes every plane distance err
+// towards "box is bigger" for either sign of the direction.
+struct RayF {
+  float odn[3], oup[3], inv[3];
+};
+__device__ __forceinline__ float f_down(double x) {
+  float f = (float)x;
+  return ((double)f > x) ? nextafterf(f, -INFINITY) : f;
+}
+__device__ __forceinline__ float f_up(double x) {
+  float f = (float)x;
+  return ((double)f < x) ? nextafterf(f, INFINITY) : f;
+}
+// The reciprocal direction (Ray::inv_d, src/pathtracer/ray.h:41) is only used by
+// the box test, so it is formed in float: conversion + v_rcp_f32 (1 ulp).
+__device__ __forceinline__ RayF make_rayf(v3 o, v3 d) {
+  RayF r;
+  r.odn[0] = f_down(o.x); r.odn[1] = f_down(o.y); r.odn[2] = f_down(o.z);
+  r.oup[0] = f_up(o.x); r.oup[1] = f_up(o.y); r.oup[2] = f_up(o.z);
+  r.inv[0] = __builtin_amdgcn_rcpf((float)d.x);
+  r.inv[1] = __builtin_amdgcn_rcpf((float)d.y);
+  r.inv[2] = __builtin_amdgcn_rcpf((float)d.z);
+  return r;
+}
+// Conservative FP32 version of BBox::intersect (src/scene/bbox.cpp:10-47).
+// Each plane distance carries at most 4 float roundings (difference, direction
+// conversion, reciprocal, product): relative error < 2^-21.5. The entry distance
+// is therefore lowered and the exit distance raised by 2^-20 relative before the
+// reference's four rejection tests are applied. fminf/fmaxf drop NaNs (a
+// direction component of exactly 0), and the tests are written so that a NaN
+// accepts.
+__device__ __forceinline__ bool slab_f(const float lo[3], const float hi[3], const RayF &r, float min_t_dn,
+                                       float max_t_up, float &tnear) {
+  const float x0 = (lo[0] - r.oup[0]) * r.inv[0], x1 = (hi[0] - r.odn[0]) * r.inv[0];
+  const float y0 = (lo[1] - r.oup[1]) * r.inv[1], y1 = (hi[1] - r.odn[1]) * r.inv[1];
+  const float z0 = (lo[2] - r.oup[2]) * r.inv[2], z1 = (hi[2] - r.odn[2]) * r.inv[2];
+  float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
+  float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+  const float k = 9.53674316e-07f;  // 2^-20
+  tn = tn - fabsf(tn) * k;
+  tf = tf + fabsf(tf) * k;
+  tnear = tn;
+  return !(tn > tf || tn > max_t_up || tf < min_t_dn || tf < 0.f);
 }
 
 // Per-lane traversal stack: the first STACK_LDS levels live in LDS (entry
@@ -146,108 +192,227 @@ struct Hit {
   int32_t prim;
 };
 
-// Closest hit (ANY = false) or any hit (ANY = true) of one ray.
+__device__ __forceinline__ void cswap(float &ta, int32_t &ca, float &tb, int32_t &cb) {
+  if (tb < ta) {
+    const float t = ta; ta = tb; tb = t;
+    const int32_t c = ca; ca = cb; cb = c;
+  }
+}
+
+// State of one ray's walk.
 //
-// The reference walks the tree with an explicit stack in a fixed order and keeps
-// the first of equally distant hits (src/scene/bvh.cpp:164-200). Primitives are
-// stored here in exactly that visiting order, so "closest t, then lowest index"
-// reproduces its answer for ANY traversal order; this one goes near child first
-// and drops stacked subtrees that start beyond the current hit.
-//
-template <bool ANY, bool COUNT>
-__device__ __forceinline__ bool traverse(const DevScene &S, v3 o, v3 d, double min_t, double max_t0, Hit &hit,
-                                         const TravStack &stack, uint32_t &n_nodes, uint32_t &n_tests) {
-  const v3 inv = V(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);  // src/pathtracer/ray.h:41
-  double best_t = max_t0;
-  hit.prim = -1;
-  hit.t = max_t0;
-  hit.u = hit.v = 0;
-  int sp = 0;
-  int32_t cur = S.root_code;
-  for (;;) {
-    if (cur >= 0) {
-      const DevNode *nd = S.nodes + cur;
-      if (COUNT) n_nodes += 2;
-      double tl, tr;
-      const bool hl = nd->left != LEAF_EMPTY && slab(nd->lb, o, inv, min_t, best_t, tl);
-      const bool hr = nd->right != LEAF_EMPTY && slab(nd->rb, o, inv, min_t, best_t, tr);
-      const int32_t cl = nd->left, cr = nd->right;
-      if (hl && hr) {
-        const bool left_first = tl <= tr;
-        const int32_t far_c = left_first ? cr : cl;
-        const double far_t = left_first ? tr : tl;
-        // entry distance rounded DOWN to float: may only delay a cull
-        float ft = (float)far_t;
-        if ((double)ft > far_t) ft = nextafterf(ft, -INFINITY);
-        if (!(far_t == far_t)) ft = -INFINITY;
-        stack.put(sp, make_uint2((uint32_t)far_c, __float_as_uint(ft)));
-        sp++;
-        cur = left_first ? cl : cr;
-        continue;
-      } else if (hl) {
-        cur = cl;
-        continue;
-      } else if (hr) {
-        cur = cr;
-        continue;
-      }
-    } else if (cur != LEAF_EMPTY) {
-      const uint32_t code = ~(uint32_t)cur;
-      const int start = (int)(code >> 4), cnt = (int)(code & 15u) + 1;
-      for (int p = start; p < start + cnt; p++) {
-        if (COUNT) n_tests++;
-        const double *P = S.prim + (size_t)p * PRIM_STRIDE;
-        const int32_t info = S.prim_info[p];
-        double t, u = 0, v = 0;
-        bool ok;
-        if (!(info & 1)) {
-          // Triangle::test, src/scene/triangle.cpp:25-44
-          const v3 p1 = V(P[0], P[1], P[2]), e1 = V(P[3], P[4], P[5]), e2 = V(P[6], P[7], P[8]);
-          const v3 normal = V(P[9], P[10], P[11]);
-          if (vdot(normal, d) == 0) continue;
-          const v3 s = vsub(o, p1), s1 = vcross(d, e2), s2 = vcross(s, e1);
-          const double rse1 = 1 / (vdot(s1, e1));
-          t = vdot(s2, e2) * rse1;
-          u = vdot(s1, s) * rse1;
-          v = vdot(s2, d) * rse1;
-          ok = !(t < min_t || t > best_t || u < 0 || v < 0 || u + v > 1);
-        } else {
-          // Sphere::test / Sphere::intersect, src/scene/sphere.cpp:11-72
-          const v3 c = V(P[0], P[1], P[2]);
-          const double r2 = P[3];
-          const v3 ominc = vsub(o, c);
-          const double a = vdot(d, d), b = 2 * vdot(ominc, d), cc = vdot(ominc, ominc) - r2;
-          const double discr = b * b - 4 * a * cc;
-          if (discr < 0) continue;
-          const double r2a = 1 / (2 * a);
-          const double b2a = -b * r2a, sq = sqrt(discr) * r2a;
-          const double t1 = b2a - sq, t2 = b2a + sq;
-          if (t1 <= best_t && t1 >= min_t) { t = t1; ok = true; }
-          else if (t2 <= best_t && t2 >= min_t) { t = t2; ok = true; }
-          else { t = 0; ok = false; }
-        }
-        if (ok) {
-          // ok means min_t <= t <= best_t. Every such hit shortens the ray
-          // (r.max_t = t); it is RECORDED when strictly closer than anything
-          // before (bvh.cpp:187), or equally close as the recorded hit but
-          // earlier in the reference's visiting order (lower index here).
-          if (ANY) {
-            if (t < max_t0) { hit.prim = p; hit.t = t; return true; }
-          } else if (t < best_t || (hit.prim >= 0 && p < hit.prim)) {
-            hit.prim = p; hit.t = t; hit.u = u; hit.v = v;
-          }
-          best_t = t;
-        }
-      }
-    }
-    // pop, skipping subtrees that begin beyond the current hit
-    for (;;) {
-      if (sp == 0) return hit.prim >= 0;
+// The reference walks its binary tree with an explicit stack in a fixed order
+// and keeps the first of equally distant hits (src/scene/bvh.cpp:164-200).
+// Primitives are stored here in exactly that visiting order, so "closest t, then
+// lowest index" reproduces its answer for ANY traversal order and ANY tree over
+// the same primitives; this walk takes the nearest child of a 4-wide node first
+// and drops stacked subtrees that start beyond the current hit. Primitive tests
+// are the reference's, in FP64.
+struct Walk {
+  v3 o, d;
+  RayF rf;
+  double min_t, max_t0, best_t;
+  float min_f, best_f;
+  Hit hit;
+  int sp;
+  int32_t cur;
+
+  __device__ __forceinline__ void begin(const DevScene &S, v3 o_, v3 d_, double tmin, double tmax) {
+    o = o_; d = d_;
+    rf = make_rayf(o, d);
+    min_t = tmin; max_t0 = tmax;
+    min_f = f_down(tmin);
+    best_t = tmax;
+    best_f = f_up(tmax);
+    hit.prim = -1; hit.t = tmax; hit.u = 0; hit.v = 0;
+    sp = 0;
+    cur = S.root_code;
+  }
+
+  // pop, skipping subtrees that begin beyond the current hit
+  __device__ __forceinline__ void pop(const TravStack &stack) {
+    cur = CHILD_EMPTY;
+    while (sp > 0) {
       sp--;
       const uint2 e = stack.get(sp);
-      if ((double)__uint_as_float(e.y) > best_t) continue;
+      if (__uint_as_float(e.y) > best_f) continue;
       cur = (int32_t)e.x;
       break;
+    }
+  }
+
+  // cur >= 0: test the node's four child boxes, descend into the nearest
+  template <bool COUNT>
+  __device__ __forceinline__ void node_step(const DevScene &S, const TravStack &stack, uint32_t &n_nodes) {
+    const float FINF = INFINITY;
+    const uint4 *np = reinterpret_cast<const uint4 *>(S.nodes + cur);
+    const uint4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3];
+    if (COUNT) n_nodes += 4;
+    const float org[3] = {__uint_as_float(w0.x), __uint_as_float(w0.y), __uint_as_float(w0.z)};
+    const float sc[3] = {__uint_as_float((w0.w & 0xffu) << 23), __uint_as_float(((w0.w >> 8) & 0xffu) << 23),
+                         __uint_as_float(((w0.w >> 16) & 0xffu) << 23)};
+    // 24 quantised bytes: w1.xyzw, w2.xy; codes: w2.zw, w3.xy
+    const uint32_t qw[6] = {w1.x, w1.y, w1.z, w1.w, w2.x, w2.y};
+    int32_t c[4] = {(int32_t)w2.z, (int32_t)w2.w, (int32_t)w3.x, (int32_t)w3.y};
+    float t[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      float lo[3], hi[3];
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+        const int bl = k * 6 + a, bh = k * 6 + 3 + a;
+        const float ql = (float)((qw[bl >> 2] >> ((bl & 3) * 8)) & 0xffu);
+        const float qh = (float)((qw[bh >> 2] >> ((bh & 3) * 8)) & 0xffu);
+        lo[a] = fmaf(ql, sc[a], org[a]);  // exact: see DevNode
+        hi[a] = fmaf(qh, sc[a], org[a]);
+      }
+      if (!(c[k] != CHILD_EMPTY && slab_f(lo, hi, rf, min_f, best_f, t[k]))) t[k] = FINF;
+      // an accepted child whose entry distance came out NaN still has to be visited
+      if (t[k] != t[k]) t[k] = -FINF;
+    }
+    cswap(t[0], c[0], t[1], c[1]);
+    cswap(t[2], c[2], t[3], c[3]);
+    cswap(t[0], c[0], t[2], c[2]);
+    cswap(t[1], c[1], t[3], c[3]);
+    cswap(t[1], c[1], t[2], c[2]);
+    if (t[0] < FINF) {
+      if (t[3] < FINF) { stack.put(sp, make_uint2((uint32_t)c[3], __float_as_uint(t[3]))); sp++; }
+      if (t[2] < FINF) { stack.put(sp, make_uint2((uint32_t)c[2], __float_as_uint(t[2]))); sp++; }
+      if (t[1] < FINF) { stack.put(sp, make_uint2((uint32_t)c[1], __float_as_uint(t[1]))); sp++; }
+      cur = c[0];
+    } else {
+      pop(stack);
+    }
+  }
+
+  // cur is a primitive: the reference's FP64 test; returns true when the walk is over
+  template <bool ANY, bool COUNT>
+  __device__ __forceinline__ bool prim_step(const DevScene &S, const TravStack &stack, uint32_t &n_tests) {
+    const int p = (int)~(uint32_t)cur;
+    if (COUNT) n_tests++;
+    const double *P = S.prim + (size_t)p * PRIM_STRIDE;
+    const int32_t info = reinterpret_cast<const int32_t *>(P + 9)[0];
+    double t = 0, u = 0, v = 0;
+    bool ok = false;
+    if (!(info & 1)) {
+      // Triangle::test, src/scene/triangle.cpp:25-44
+      const v3 p1 = V(P[0], P[1], P[2]), e1 = V(P[3], P[4], P[5]), e2 = V(P[6], P[7], P[8]);
+      const v3 normal = vcross(e1, e2);
+      if (vdot(normal, d) != 0) {
+        const v3 sv = vsub(o, p1), s1 = vcross(d, e2), s2 = vcross(sv, e1);
+        const double rse1 = 1 / (vdot(s1, e1));
+        t = vdot(s2, e2) * rse1;
+        u = vdot(s1, sv) * rse1;
+        v = vdot(s2, d) * rse1;
+        ok = !(t < min_t || t > best_t || u < 0 || v < 0 || u + v > 1);
+      }
+    } else {
+      // Sphere::test / Sphere::intersect, src/scene/sphere.cpp:11-72
+      const v3 c = V(P[0], P[1], P[2]);
+      const double r2 = P[3];
+      const v3 ominc = vsub(o, c);
+      const double a = vdot(d, d), b = 2 * vdot(ominc, d), cc = vdot(ominc, ominc) - r2;
+      const double discr = b * b - 4 * a * cc;
+      if (!(discr < 0)) {
+        const double r2a = 1 / (2 * a);
+        const double b2a = -b * r2a, sq = sqrt(discr) * r2a;
+        const double t1 = b2a - sq, t2 = b2a + sq;
+        if (t1 <= best_t && t1 >= min_t) { t = t1; ok = true; }
+        else if (t2 <= best_t && t2 >= min_t) { t = t2; ok = true; }
+      }
+    }
+    if (ok) {
+      // ok means min_t <= t <= best_t. Every such hit shortens the ray
+      // (r.max_t = t); it is RECORDED when strictly closer than anything before
+      // (bvh.cpp:187), or equally close as the recorded hit but earlier in the
+      // reference's visiting order (lower index here).
+      if (ANY) {
+        if (t < max_t0) { hit.prim = p; hit.t = t; return true; }
+      } else if (t < best_t || (hit.prim >= 0 && p < hit.prim)) {
+        hit.prim = p; hit.t = t; hit.u = u; hit.v = v;
+      }
+      best_t = t;
+      best_f = f_up(t);
+    }
+    pop(stack);
+    return cur == CHILD_EMPTY;
+  }
+};
+
+// Traces a list of rays. Policy: load(i, o, d, min_t, max_t) reads ray i;
+// store(i, hit, found) writes its result.
+//
+// PERSISTENT = false: one ray per lane per grid-stride step.
+// PERSISTENT = true: a wave claims chunks of the list and every lane fetches the
+// next ray as soon as its own is finished; lanes that hold a primitive wait until
+// enough of them do, so the FP64 test runs on a fuller wave.
+template <bool ANY, bool COUNT, bool PERSISTENT, class Policy>
+__device__ __forceinline__ void trace_rays(const DevScene &S, const Policy &pol, uint32_t n, uint32_t *grab,
+                                           const TravStack &stack, uint32_t &n_nodes, uint32_t &n_tests) {
+  Walk w;
+  if (!PERSISTENT) {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+      v3 o, d;
+      double tmin, tmax;
+      pol.load(i, o, d, tmin, tmax);
+      w.begin(S, o, d, tmin, tmax);
+      while (w.cur != CHILD_EMPTY) {
+        if (w.cur >= 0) w.template node_step<COUNT>(S, stack, n_nodes);
+        else if (w.template prim_step<ANY, COUNT>(S, stack, n_tests)) break;
+      }
+      pol.store(i, w.hit, w.hit.prim >= 0);
+    }
+    return;
+  }
+  constexpr uint32_t GRAB = 256;
+  constexpr int PRIM_LANES = 20;
+  uint32_t next = 0, end = 0, idx = 0;
+  bool exhausted = false, active = false;
+  const int lane = threadIdx.x & 63;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  w.begin(S, V(0, 0, 0), V(0, 0, 1), 0, 0);
+  w.cur = CHILD_EMPTY;
+  for (;;) {
+    const unsigned long long idle = __ballot(!active);
+    if (idle) {
+      if (next >= end && !exhausted) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(grab, GRAB);
+        base = __shfl(base, 0);
+        next = base;
+        end = base + GRAB < n ? base + GRAB : n;
+        if (base >= n) { exhausted = true; next = end = 0; }
+      }
+      if (next < end) {
+        const uint32_t mine = next + (uint32_t)__popcll(idle & below);
+        if (!active && mine < end) {
+          idx = mine;
+          v3 o, d;
+          double tmin, tmax;
+          pol.load(idx, o, d, tmin, tmax);
+          w.begin(S, o, d, tmin, tmax);
+          active = true;
+        }
+        const uint32_t taken = (uint32_t)__popcll(idle);
+        next = next + taken < end ? next + taken : end;
+      }
+    }
+    if (!__ballot(active)) {
+      if (exhausted) break;
+      continue;
+    }
+    if (active && w.cur >= 0) w.template node_step<COUNT>(S, stack, n_nodes);
+    bool done = active && w.cur == CHILD_EMPTY;
+    const bool on_prim = active && w.cur < 0 && w.cur != CHILD_EMPTY;
+    const unsigned long long pm = __ballot(on_prim);
+    const unsigned long long nm = __ballot(active && w.cur >= 0);
+    if (pm && (__popcll(pm) >= PRIM_LANES || nm == 0)) {
+      if (on_prim) done = w.template prim_step<ANY, COUNT>(S, stack, n_tests);
+    }
+    if (done) {
+      pol.store(idx, w.hit, w.hit.prim >= 0);
+      active = false;
     }
   }
 }
@@ -336,6 +501,8 @@ __device__ __forceinline__ v3 light_sample_L(const DevScene &S, int li, v3 p, do
 
 // ------------------------------------------------------------------ kernels
 __global__ void k_set_counts(Ctl *ctl, uint32_t n_cur) {
+  ctl->grab_extend = 0;
+  ctl->grab_shadow = 0;
   ctl->n_cur = n_cur;
   ctl->n_next = 0;
   ctl->n_shadow = 0;
@@ -350,6 +517,8 @@ __global__ void k_advance(Ctl *ctl, int count_vertices) {
   ctl->n_cur = ctl->n_next;
   ctl->n_next = 0;
   ctl->n_shadow = 0;
+  ctl->grab_extend = 0;
+  ctl->grab_shadow = 0;
 }
 
 // Camera::generate_ray, src/pathtracer/camera.cpp:190-203
@@ -405,26 +574,35 @@ __global__ void k_generate_primary(FrameParams fp, const double *__restrict__ sx
 // list position, light sample q of vertex i at slot i*nls + q) and the queues are
 // ordered index lists built by ballot / prefix-sum compaction: no atomics, and
 // the order is the same on every run.
-template <bool COUNT>
-__global__ void __launch_bounds__(256)
-    k_extend(DevScene S, RayQ q, const int32_t *__restrict__ list, HitBuf hb, Ctl *ctl, double min_t, double max_t,
-             uint2 *gstack) {
-  extern __shared__ uint2 lds_stack[];
-  const TravStack stack{lds_stack, gstack, gridDim.x * blockDim.x, blockIdx.x * blockDim.x + threadIdx.x};
-  const uint32_t n = ctl->n_cur;
-  const uint32_t stride = gridDim.x * blockDim.x;
-  uint32_t cn = 0, ct = 0;
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+struct ExtendPolicy {
+  RayQ q;
+  const int32_t *list;
+  HitBuf hb;
+  double min_t, max_t;
+  __device__ __forceinline__ void load(uint32_t i, v3 &o, v3 &d, double &tmin, double &tmax) const {
     const uint32_t j = list ? (uint32_t)list[i] : i;
-    const v3 o = V(q.o[0][j], q.o[1][j], q.o[2][j]);
-    const v3 d = V(q.d[0][j], q.d[1][j], q.d[2][j]);
-    Hit h;
-    traverse<false, COUNT>(S, o, d, min_t, max_t, h, stack, cn, ct);
+    o = V(q.o[0][j], q.o[1][j], q.o[2][j]);
+    d = V(q.d[0][j], q.d[1][j], q.d[2][j]);
+    tmin = min_t;
+    tmax = max_t;
+  }
+  __device__ __forceinline__ void store(uint32_t i, const Hit &h, bool) const {
     hb.prim[i] = h.prim;
     hb.t[i] = h.t;
     hb.u[i] = h.u;
     hb.v[i] = h.v;
   }
+};
+
+template <bool COUNT, bool PERSISTENT>
+__global__ void __launch_bounds__(256)
+    k_extend(DevScene S, RayQ q, const int32_t *__restrict__ list, HitBuf hb, Ctl *ctl, double min_t, double max_t,
+             uint2 *gstack) {
+  extern __shared__ uint2 lds_stack[];
+  const TravStack stack{lds_stack, gstack, gridDim.x * blockDim.x, blockIdx.x * blockDim.x + threadIdx.x};
+  uint32_t cn = 0, ct = 0;
+  const ExtendPolicy pol{q, list, hb, min_t, max_t};
+  trace_rays<false, COUNT, PERSISTENT>(S, pol, ctl->n_cur, &ctl->grab_extend, stack, cn, ct);
   if (COUNT) {
     atomicAdd(&ctl->st_nodes, (unsigned long long)cn);
     atomicAdd(&ctl->st_tests, (unsigned long long)ct);
@@ -434,25 +612,25 @@ __global__ void __launch_bounds__(256)
 // Shadow rays: light sampling needs only "is anything in the way"
 // (pathtracer.cpp:127); hemisphere sampling needs the closest hit's emission
 // (pathtracer.cpp:79-82). vis[slot]: 2 = ray pending, 1 = light sample counts, 0 = not.
-template <bool HEMI, bool COUNT>
-__global__ void __launch_bounds__(256)
-    k_shadow(DevScene S, ShadowQ sq, VertexBuf vb, Ctl *ctl, int32_t nls, uint2 *gstack) {
-  extern __shared__ uint2 lds_stack[];
-  const TravStack stack{lds_stack, gstack, gridDim.x * blockDim.x, blockIdx.x * blockDim.x + threadIdx.x};
-  const uint32_t n = ctl->n_shadow;
-  const uint32_t stride = gridDim.x * blockDim.x;
-  uint32_t cn = 0, ct = 0;
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+template <bool HEMI>
+struct ShadowPolicy {
+  DevScene S;
+  ShadowQ sq;
+  VertexBuf vb;
+  uint32_t nls;
+  __device__ __forceinline__ void load(uint32_t i, v3 &o, v3 &d, double &tmin, double &tmax) const {
     const int32_t slot = sq.slot[i];
-    const uint32_t e = (uint32_t)slot / (uint32_t)nls;
-    const v3 o = V(vb.hp[0][e], vb.hp[1][e], vb.hp[2][e]);
-    const v3 d = V(sq.d[0][slot], sq.d[1][slot], sq.d[2][slot]);
-    Hit h;
+    const uint32_t e = (uint32_t)slot / nls;
+    o = V(vb.hp[0][e], vb.hp[1][e], vb.hp[2][e]);
+    d = V(sq.d[0][slot], sq.d[1][slot], sq.d[2][slot]);
+    tmin = PT_EPS_D;
+    tmax = HEMI ? (double)INFINITY : sq.max_t[slot];
+  }
+  __device__ __forceinline__ void store(uint32_t i, const Hit &h, bool found) const {
+    const int32_t slot = sq.slot[i];
     if (!HEMI) {
-      const bool occluded = traverse<true, COUNT>(S, o, d, PT_EPS_D, sq.max_t[slot], h, stack, cn, ct);
-      vb.vis[slot] = occluded ? 0 : 1;
+      vb.vis[slot] = found ? 0 : 1;
     } else {
-      const bool found = traverse<false, COUNT>(S, o, d, PT_EPS_D, (double)INFINITY, h, stack, cn, ct);
       if (found) {
         const int32_t m = S.prim_info[h.prim] >> 1;
         v3 light_L = V(0, 0, 0);
@@ -465,6 +643,17 @@ __global__ void __launch_bounds__(256)
       vb.vis[slot] = found ? 1 : 0;
     }
   }
+};
+
+template <bool HEMI, bool COUNT, bool PERSISTENT>
+__global__ void __launch_bounds__(256)
+    k_shadow(DevScene S, ShadowQ sq, VertexBuf vb, Ctl *ctl, int32_t nls, uint2 *gstack) {
+  extern __shared__ uint2 lds_stack[];
+  const TravStack stack{lds_stack, gstack, gridDim.x * blockDim.x, blockIdx.x * blockDim.x + threadIdx.x};
+  uint32_t cn = 0, ct = 0;
+  const ShadowPolicy<HEMI> pol{S, sq, vb, (uint32_t)nls};
+  if (HEMI) trace_rays<false, COUNT, PERSISTENT>(S, pol, ctl->n_shadow, &ctl->grab_shadow, stack, cn, ct);
+  else trace_rays<true, COUNT, PERSISTENT>(S, pol, ctl->n_shadow, &ctl->grab_shadow, stack, cn, ct);
   if (COUNT) {
     atomicAdd(&ctl->st_nodes, (unsigned long long)cn);
     atomicAdd(&ctl->st_tests, (unsigned long long)ct);
@@ -1134,6 +1323,50 @@ int ptamd_set_profiling(ptamd_context *c, int32_t events, int32_t counters) {
   return PTAMD_OK;
 }
 
+// Fills the quantised boxes of a 4-wide node: per axis a grid step 2^e and an
+// origin on that grid such that every child plane lies within 255 steps and every
+// decoded plane origin + q * 2^e is exactly representable in float. lo planes are
+// rounded down, hi planes up (checked in double, where all of this is exact).
+static bool quantize_node(DevNode &n, const double boxes[][6], int nk) {
+  n.exps = 0;
+  for (int a = 0; a < 3; a++) {
+    double lo = INFINITY, hi = -INFINITY;
+    for (int k = 0; k < nk; k++) { lo = std::min(lo, boxes[k][a]); hi = std::max(hi, boxes[k][3 + a]); }
+    if (!(std::isfinite(lo) && std::isfinite(hi)) || hi < lo) return false;
+    int e;
+    {
+      const double ext = std::max(hi - lo, 1e-30);
+      (void)std::frexp(ext / 255.0, &e);  // ext / 255 < 2^e
+      e = std::max(e, -100);
+    }
+    for (;; e++) {
+      if (e > 100) return false;
+      const double s = std::ldexp(1.0, e);
+      const double k0 = std::floor(lo / s);
+      if (std::fabs(k0) > 4194304.0) continue;  // origin + 255 steps must stay below 2^24 steps
+      const double org = k0 * s;
+      if (std::ceil((hi - org) / s) > 255.0) continue;
+      bool ok = true;
+      uint8_t q[4][2];
+      for (int k = 0; k < nk && ok; k++) {
+        double ql = std::floor((boxes[k][a] - org) / s), qh = std::ceil((boxes[k][3 + a] - org) / s);
+        while (ql > 0 && org + ql * s > boxes[k][a]) ql -= 1;
+        while (org + qh * s < boxes[k][3 + a]) qh += 1;
+        if (ql < 0 || qh > 255 || org + ql * s > boxes[k][a]) { ok = false; break; }
+        // the device evaluates fmaf(q, s, org) in float: must be exact
+        if ((double)(float)(org + ql * s) != org + ql * s || (double)(float)(org + qh * s) != org + qh * s) { ok = false; break; }
+        q[k][0] = (uint8_t)ql; q[k][1] = (uint8_t)qh;
+      }
+      if (!ok || (double)(float)org != org) continue;
+      n.org[a] = (float)org;
+      n.exps |= (uint32_t)(e + 127) << (8 * a);
+      for (int k = 0; k < nk; k++) { n.q[k][a] = q[k][0]; n.q[k][3 + a] = q[k][1]; }
+      break;
+    }
+  }
+  return true;
+}
+
 int ptamd_upload_scene(ptamd_context *c, const ptamd_scene_desc *d) {
   if (!c || !d) { ptamd::set_error("null argument"); return PTAMD_ERR_ARG; }
   HIPCHK(hipSetDevice(c->device));
@@ -1165,7 +1398,7 @@ int ptamd_upload_scene(ptamd_context *c, const ptamd_scene_desc *d) {
       if (d->node_count[n] > 0) {
         const int s = d->node_start[n], cnt = d->node_count[n];
         if (s < 0 || s + cnt > NP) { ptamd::set_error("BVH leaf range outside the primitive array"); return PTAMD_ERR_SCENE; }
-        if (cnt > 16) { ptamd::set_error("BVH leaves of more than 16 primitives are not supported"); return PTAMD_ERR_SCENE; }
+        if (cnt > 4) { ptamd::set_error("BVH leaves of more than 4 primitives are not supported (the reference builds with max_leaf_size = 4)"); return PTAMD_ERR_SCENE; }
         leaf_new_start[n] = (int32_t)visit_order.size();
         for (int p = s; p < s + cnt; p++) {
           if (prim_seen[p]) { ptamd::set_error("primitive referenced by two leaves"); return PTAMD_ERR_SCENE; }
@@ -1183,37 +1416,113 @@ int ptamd_upload_scene(ptamd_context *c, const ptamd_scene_desc *d) {
     if (d->prim_material[p] < 0 || d->prim_material[p] >= d->n_materials) { ptamd::set_error("primitive material index out of range"); return PTAMD_ERR_SCENE; }
     if (d->prim_type[p] != PTAMD_PRIM_TRIANGLE && d->prim_type[p] != PTAMD_PRIM_SPHERE) { ptamd::set_error("unknown primitive type"); return PTAMD_ERR_SCENE; }
   }
-  // ---- interior nodes get dense indices; children are coded
-  std::vector<int32_t> interior_index(N, -1);
-  int n_interior = 0;
-  for (int n = 0; n < N; n++)
-    if (seen[n] && d->node_count[n] <= 0) interior_index[n] = n_interior++;
-  auto code_of = [&](int n) -> int32_t {
-    if (d->node_count[n] > 0) return ~(int32_t)(((uint32_t)leaf_new_start[n] << 4) | (uint32_t)(d->node_count[n] - 1));
-    return interior_index[n];
-  };
-  std::vector<DevNode> nodes((size_t)std::max(n_interior, 1));
-  memset(nodes.data(), 0, nodes.size() * sizeof(DevNode));
-  int32_t root_code;
-  if (d->node_count[d->root] > 0) {
-    // a single-leaf tree: wrap it in one interior node whose other child is empty
-    DevNode &nd = nodes[0];
-    memcpy(nd.lb, d->node_bbox + 6 * (size_t)d->root, 48);
-    nd.left = code_of(d->root);
-    nd.right = LEAF_EMPTY;
-    root_code = 0;
-  } else {
-    for (int n = 0; n < N; n++) {
-      if (interior_index[n] < 0) continue;
-      DevNode &nd = nodes[interior_index[n]];
-      const int l = d->node_left[n], r = d->node_right[n];
-      memcpy(nd.lb, d->node_bbox + 6 * (size_t)l, 48);
-      memcpy(nd.rb, d->node_bbox + 6 * (size_t)r, 48);
-      nd.left = code_of(l);
-      nd.right = code_of(r);
+  // ---- collapse the binary tree into 4-wide nodes whose children are nodes or
+  // single primitives. new_index[p] = position of the caller's primitive p in
+  // visiting order (the device's primitive index).
+  std::vector<int32_t> new_index(NP);
+  for (int i = 0; i < NP; i++) new_index[visit_order[i]] = i;
+  struct Item { int32_t node; int32_t prim; };  // node >= 0: a node of the caller's tree; else the caller's primitive
+  auto prim_box = [&](int p, double bb[6]) {
+    const double *P = d->prim_pos + 9 * (size_t)p;
+    if (d->prim_type[p] == PTAMD_PRIM_TRIANGLE) {
+      for (int k = 0; k < 3; k++) {
+        bb[k] = std::min(P[k], std::min(P[3 + k], P[6 + k]));
+        bb[3 + k] = std::max(P[k], std::max(P[3 + k], P[6 + k]));
+      }
+    } else {  // o -/+ Vector3D(r, r, r), src/scene/sphere.h:32-34
+      for (int k = 0; k < 3; k++) { bb[k] = P[k] - P[3]; bb[3 + k] = P[k] + P[3]; }
     }
-    root_code = interior_index[d->root];
+  };
+  auto item_box = [&](const Item &it, double bb[6]) {
+    if (it.node >= 0) memcpy(bb, d->node_bbox + 6 * (size_t)it.node, 48);
+    else prim_box(it.prim, bb);
+  };
+  auto area = [](const double bb[6]) {
+    const double ex = bb[3] - bb[0], ey = bb[4] - bb[1], ez = bb[5] - bb[2];
+    return ex * ey + ey * ez + ez * ex;
+  };
+  auto expand = [&](const Item &it, std::vector<Item> &out) {
+    const int n = it.node;
+    if (d->node_count[n] > 0) {
+      for (int p = d->node_start[n]; p < d->node_start[n] + d->node_count[n]; p++) out.push_back({-1, p});
+    } else {
+      out.push_back({d->node_left[n], -1});
+      out.push_back({d->node_right[n], -1});
+    }
+  };
+  auto expanded_size = [&](const Item &it) { return d->node_count[it.node] > 0 ? d->node_count[it.node] : 2; };
+  std::vector<DevNode> nodes;
+  nodes.reserve((size_t)NP / 2 + 4);
+  int depth4 = 0;
+  struct Frame { int32_t node4; int slot; Item item; int depth; };
+  std::vector<Frame> work;
+  // a single-primitive leaf is just that primitive
+  auto normalize = [&](Item it) {
+    if (it.node >= 0 && d->node_count[it.node] == 1) return Item{-1, d->node_start[it.node]};
+    return it;
+  };
+  int32_t root_code;
+  {
+    DevNode rootn;
+    memset(&rootn, 0, sizeof rootn);
+    for (int k = 0; k < 4; k++) rootn.child[k] = CHILD_EMPTY;
+    nodes.push_back(rootn);
+    root_code = 0;
+    work.push_back({0, -1, normalize(Item{d->root, -1}), 1});
   }
+  // `work` entries with slot == -1 fill node `node4` with the children of `item`
+  while (!work.empty()) {
+    Frame f = work.back();
+    work.pop_back();
+    depth4 = std::max(depth4, f.depth);
+    std::vector<Item> kids;
+    if (f.item.node < 0) {
+      kids.push_back(f.item);  // the whole scene is one primitive
+    } else {
+      expand(f.item, kids);
+      for (auto &k : kids) k = normalize(k);
+      // open the largest openable child while the result still fits four slots
+      for (;;) {
+        int best = -1;
+        double best_area = -1;
+        for (size_t k = 0; k < kids.size(); k++) {
+          if (kids[k].node < 0) continue;
+          if ((int)kids.size() - 1 + expanded_size(kids[k]) > 4) continue;
+          double bb[6];
+          item_box(kids[k], bb);
+          const double a = area(bb);
+          if (a > best_area) { best_area = a; best = (int)k; }
+        }
+        if (best < 0) break;
+        const Item it = kids[best];
+        kids.erase(kids.begin() + best);
+        std::vector<Item> sub;
+        expand(it, sub);
+        for (auto &k : sub) kids.push_back(normalize(k));
+      }
+    }
+    double boxes[4][6];
+    for (size_t k = 0; k < kids.size(); k++) item_box(kids[k], boxes[k]);
+    if (!quantize_node(nodes[f.node4], boxes, (int)kids.size())) {
+      ptamd::set_error("BVH node box cannot be represented (non-finite or out of float range)");
+      return PTAMD_ERR_SCENE;
+    }
+    for (size_t k = 0; k < kids.size(); k++) {
+      if (kids[k].node < 0) {
+        nodes[f.node4].child[k] = ~new_index[kids[k].prim];
+      } else {
+        DevNode nn;
+        memset(&nn, 0, sizeof nn);
+        for (int j = 0; j < 4; j++) nn.child[j] = CHILD_EMPTY;
+        const int32_t id = (int32_t)nodes.size();
+        nodes.push_back(nn);
+        nodes[f.node4].child[k] = id;
+        work.push_back({id, -1, kids[k], f.depth + 1});
+      }
+    }
+  }
+  // deepest stack: three siblings pushed per level
+  max_depth = 3 * depth4;
   // ---- primitive records in visiting order
   std::vector<double> prim((size_t)NP * PRIM_STRIDE, 0.0), nrm((size_t)NP * 9);
   std::vector<int32_t> info(NP);
@@ -1222,21 +1531,17 @@ int ptamd_upload_scene(ptamd_context *c, const ptamd_scene_desc *d) {
     const double *P = d->prim_pos + 9 * (size_t)p;
     double *R = prim.data() + (size_t)i * PRIM_STRIDE;
     if (d->prim_type[p] == PTAMD_PRIM_TRIANGLE) {
-      // e1 = p2 - p1, e2 = p3 - p1, normal = cross(e1, e2): one rounding each,
-      // identical to evaluating them per ray; this file is built with
-      // -ffp-contract=off so the host compiler cannot fuse them either
-      volatile double e1x = P[3] - P[0], e1y = P[4] - P[1], e1z = P[5] - P[2];
-      volatile double e2x = P[6] - P[0], e2y = P[7] - P[1], e2z = P[8] - P[2];
-      volatile double a0 = e1y * e2z, a1 = e1z * e2y, b0 = e1z * e2x, b1 = e1x * e2z, c0 = e1x * e2y, c1 = e1y * e2x;
+      // e1 = p2 - p1, e2 = p3 - p1: one rounding each, identical to evaluating
+      // them per ray
       R[0] = P[0]; R[1] = P[1]; R[2] = P[2];
-      R[3] = e1x; R[4] = e1y; R[5] = e1z;
-      R[6] = e2x; R[7] = e2y; R[8] = e2z;
-      R[9] = a0 - a1; R[10] = b0 - b1; R[11] = c0 - c1;
+      R[3] = P[3] - P[0]; R[4] = P[4] - P[1]; R[5] = P[5] - P[2];
+      R[6] = P[6] - P[0]; R[7] = P[7] - P[1]; R[8] = P[8] - P[2];
       info[i] = d->prim_material[p] << 1;
     } else {
       R[0] = P[0]; R[1] = P[1]; R[2] = P[2]; R[3] = P[4];
       info[i] = (d->prim_material[p] << 1) | 1;
     }
+    memcpy(R + 9, &info[i], 4);
     memcpy(nrm.data() + (size_t)i * 9, d->prim_nrm + 9 * (size_t)p, 72);
   }
   free_scene(c);
@@ -1296,6 +1601,10 @@ int ptamd_frame_begin(ptamd_context *c, const ptamd_render_params *p) {
 
 // Launch shape of the traversal kernels: 256-thread workgroups, STACK_LDS stack
 // levels per lane in LDS, the rest (if the tree is deeper) in a global strip.
+// false: one ray per lane per grid-stride step; true: persistent waves that refill
+// idle lanes (see trace_rays). Measured on MI355X; the simple form wins.
+constexpr bool PERSIST = false;
+
 struct TravLaunch {
   int block, grid;
   size_t lds;
@@ -1305,10 +1614,12 @@ static int traversal_launch(ptamd_context *c, TravLaunch *t) {
   t->block = 256;
   t->lds = (size_t)t->block * std::min(c->S.stack_cap, (int32_t)STACK_LDS) * sizeof(uint2);
   // resident workgroups per CU: bounded by LDS (160 KiB per CU) and by registers
-  // (about 5 waves per SIMD); twice that many in the grid so that the tail of a
-  // launch still has work to balance
+  // (about 5 waves per SIMD). The waves are persistent, so the grid is exactly
+  // the resident set
   const int wg_per_cu = std::max(1, std::min<int>((int)((160 * 1024) / std::max<size_t>(t->lds, 1)), 5));
-  t->grid = c->num_cu * wg_per_cu * 2;
+  // persistent waves: exactly the resident set; grid-stride: twice that, so a CU
+  // always has a workgroup to start when one drains
+  t->grid = c->num_cu * wg_per_cu * (PERSIST ? 1 : 2);
   const size_t levels = (size_t)std::max(0, c->S.stack_cap - STACK_LDS);
   const size_t need = levels * (size_t)t->grid * t->block * sizeof(uint2);
   if (need > c->gstack_bytes) {
@@ -1363,8 +1674,8 @@ int ptamd_trace_pixels(ptamd_context *c, const int32_t *d_pixels, int64_t n, int
       const double max_t = depth == 1 ? fp.f_clip : (double)INFINITY;
       const int32_t *lst = depth == 1 ? nullptr : c->list[cur];
       L.begin(PTAMD_K_EXTEND);
-      if (c->prof_counters) hipLaunchKernelGGL(k_extend<true>, tgrid, tblock, lds, s, c->S, c->q[cur], lst, c->hb, c->ctl, min_t, max_t, gstack);
-      else hipLaunchKernelGGL(k_extend<false>, tgrid, tblock, lds, s, c->S, c->q[cur], lst, c->hb, c->ctl, min_t, max_t, gstack);
+      if (c->prof_counters) hipLaunchKernelGGL((k_extend<true, PERSIST>), tgrid, tblock, lds, s, c->S, c->q[cur], lst, c->hb, c->ctl, min_t, max_t, gstack);
+      else hipLaunchKernelGGL((k_extend<false, PERSIST>), tgrid, tblock, lds, s, c->S, c->q[cur], lst, c->hb, c->ctl, min_t, max_t, gstack);
       L.end();
       L.begin(PTAMD_K_SHADE);
       hipLaunchKernelGGL(k_shade, ggrid, 256, 0, s, fp, c->S, c->q[cur], lst, c->hb, c->q[cur ^ 1], c->sq, c->vb, pb, c->cp,
@@ -1377,11 +1688,11 @@ int ptamd_trace_pixels(ptamd_context *c, const int32_t *d_pixels, int64_t n, int
       if (fp.max_ray_depth > 0 && fp.nls > 0) {
         L.begin(PTAMD_K_SHADOW);
         if (fp.hemisphere) {
-          if (c->prof_counters) hipLaunchKernelGGL((k_shadow<true, true>), tgrid, tblock, lds, s, c->S, c->sq, c->vb, c->ctl, nls, gstack);
-          else hipLaunchKernelGGL((k_shadow<true, false>), tgrid, tblock, lds, s, c->S, c->sq, c->vb, c->ctl, nls, gstack);
+          if (c->prof_counters) hipLaunchKernelGGL((k_shadow<true, true, PERSIST>), tgrid, tblock, lds, s, c->S, c->sq, c->vb, c->ctl, nls, gstack);
+          else hipLaunchKernelGGL((k_shadow<true, false, PERSIST>), tgrid, tblock, lds, s, c->S, c->sq, c->vb, c->ctl, nls, gstack);
         } else {
-          if (c->prof_counters) hipLaunchKernelGGL((k_shadow<false, true>), tgrid, tblock, lds, s, c->S, c->sq, c->vb, c->ctl, nls, gstack);
-          else hipLaunchKernelGGL((k_shadow<false, false>), tgrid, tblock, lds, s, c->S, c->sq, c->vb, c->ctl, nls, gstack);
+          if (c->prof_counters) hipLaunchKernelGGL((k_shadow<false, true, PERSIST>), tgrid, tblock, lds, s, c->S, c->sq, c->vb, c->ctl, nls, gstack);
+          else hipLaunchKernelGGL((k_shadow<false, false, PERSIST>), tgrid, tblock, lds, s, c->S, c->sq, c->vb, c->ctl, nls, gstack);
         }
         L.end();
         L.begin(PTAMD_K_RESOLVE);
@@ -1547,7 +1858,7 @@ int ptamd_trace_primary(ptamd_context *c, int64_t n, const double *sx, const dou
     HIPCHK(hipMemcpyAsync(d_sy, sy + b, m * sizeof(double), hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_set_counts, 1, 1, 0, s, c->ctl, (uint32_t)m);
     hipLaunchKernelGGL(k_generate_primary, grid_for(c, 4), 256, 0, s, c->fp, d_sx, d_sy, (uint32_t)m, c->q[0]);
-    hipLaunchKernelGGL(k_extend<false>, tgrid, tblock, lds, s, c->S, c->q[0], (const int32_t *)nullptr, c->hb, c->ctl, c->fp.n_clip, c->fp.f_clip, tl.gstack);
+    hipLaunchKernelGGL((k_extend<false, PERSIST>), tgrid, tblock, lds, s, c->S, c->q[0], (const int32_t *)nullptr, c->hb, c->ctl, c->fp.n_clip, c->fp.f_clip, tl.gstack);
     HIPCHK(hipMemcpyAsync(prim.data(), c->hb.prim, m * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(t_out + b, c->hb.t, m * sizeof(double), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));

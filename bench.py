@@ -140,6 +140,9 @@ def main():
     if args.max_paths:
         dev.set_max_paths(args.max_paths)
     dev.set_profiling(events=True, counters=False)
+    # torch loads a kernel's code object on first use (tens of ms): do that for the
+    # reduction that counts a frame's samples before anything is timed
+    int(torch.zeros(8, dtype=torch.int32, device=device).sum().item())
 
     def frame(seed):
         p = cabi.make_params(args.width, args.height, ns_aa=spp, max_ray_depth=args.depth,
@@ -148,7 +151,8 @@ def main():
         return cnt
 
     for i in range(args.warmup):
-        frame(1000 + i)
+        int(frame(1000 + i).sum().item())  # warm-up covers everything a timed step does
+        dev.stats()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -156,10 +160,14 @@ def main():
     t0 = time.perf_counter()
     total_samples = 0
     agg = {"ms": [0.0] * 8, "launches": [0] * 8, "rays": 0, "shadow": 0, "vertices": 0}
+    step_ms = []
     for i in range(args.steps):
+        ts = time.perf_counter()
         cnt = frame(i)
         total_samples += int(cnt.sum().item())
+        wall = 1000.0 * (time.perf_counter() - ts)
         st = dev.stats()  # this rank's share of the frame
+        step_ms.append((wall, sum(st.kernel_ms)))
         for k in range(8):
             agg["ms"][k] += st.kernel_ms[k]
             agg["launches"][k] += st.launches[k]
@@ -177,6 +185,7 @@ def main():
         elapsed = float(t.item())
 
     if rank == 0:
+        print("step ms (wall, kernels): " + " ".join("%.1f/%.1f" % t for t in step_ms), file=sys.stderr)
         value = total_samples / elapsed
         line = {
             "metric": "path samples/sec",

@@ -181,6 +181,38 @@ int ptamd_trace_pixels(ptamd_context *ctx, const int32_t *d_pixels, int64_t n, i
  * *d_n_out (one int64 on the device). */
 int ptamd_adaptive_filter(ptamd_context *ctx, const int32_t *d_pixels_in, int64_t n, int32_t n_done,
                           const double *d_state, int32_t *d_pixels_out, int64_t *d_n_out, void *stream);
+/* A shard of a device-resident pixel list: entries offset, offset + stride,
+ * offset + 2*stride, ... below the list's length. The length is read ON THE
+ * DEVICE from *d_n when d_n is not NULL, so the host can queue the next round
+ * before the previous round's adaptive test has been read back; n_max is the
+ * host's upper bound of the length (it sizes launches and buffers). With
+ * d_n == NULL the length is n. Rank r of `world` GPUs passes offset = r,
+ * stride = world: that is the round-robin deal that replaces the reference's
+ * tile queue (src/util/work_queue.h:11-51, raytraced_renderer.cpp:297-302). */
+typedef struct ptamd_pixel_list {
+  const int32_t *d_pixels;
+  const int64_t *d_n;
+  int64_t n;
+  int64_t n_max;
+  int32_t offset, stride;
+} ptamd_pixel_list;
+/* ptamd_trace_pixels for a shard of a list whose length lives on the device. */
+int ptamd_trace_list(ptamd_context *ctx, const ptamd_pixel_list *list, int32_t sample_base,
+                     int32_t n_samples, double *d_state, void *stream);
+/* ptamd_adaptive_filter for such a list (offset 0, stride 1). */
+int ptamd_filter_list(ptamd_context *ctx, const ptamd_pixel_list *in, int32_t n_done, const double *d_state,
+                      int32_t *d_pixels_out, int64_t *d_n_out, void *stream);
+/* The exchange after a round, the counterpart of the reference's shared
+ * sampleBuffer that every worker thread writes into (pathtracer.cpp:268-271):
+ * pack gathers the state rows (6 doubles) of the shard's pixels into a dense
+ * block d_rows[k*6..]; after an all-gather of the ranks' blocks (rows_per_rank
+ * rows each), unpack writes row (i / world) of block (i % world) to the state of
+ * entry i of the whole list. Blocks of rank skip_rank are left alone (-1: none;
+ * a rank's own rows are already in place). */
+int ptamd_pack_rows(ptamd_context *ctx, const ptamd_pixel_list *list, const double *d_state, double *d_rows,
+                    void *stream);
+int ptamd_unpack_rows(ptamd_context *ctx, const ptamd_pixel_list *list, int32_t world, int32_t skip_rank,
+                      const double *d_rows, int64_t rows_per_rank, double *d_state, void *stream);
 /* pixel_sum / n and the sample count (pathtracer.cpp:268-271) for every pixel. */
 int ptamd_frame_resolve(ptamd_context *ctx, const double *d_state, double *d_hdr_out, int32_t *d_count_out,
                         void *stream);

@@ -5,7 +5,7 @@ import os
 import numpy as np
 
 from . import cabi
-from .cabi import Camera, RenderParams, SceneDesc, Stats, make_params  # noqa: F401
+from .cabi import Camera, PixelList, RenderParams, SceneDesc, Stats, make_params  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
@@ -17,6 +17,7 @@ EXPORTS = (
     "ptamd_create", "ptamd_destroy", "ptamd_upload_scene", "ptamd_set_camera", "ptamd_set_max_paths",
     "ptamd_set_profiling", "ptamd_render", "ptamd_trace_primary", "ptamd_frame_begin",
     "ptamd_trace_pixels", "ptamd_adaptive_filter", "ptamd_frame_resolve", "ptamd_get_stats",
+    "ptamd_trace_list", "ptamd_filter_list", "ptamd_pack_rows", "ptamd_unpack_rows",
     "ptamd_tonemap_rgba8", "ptamd_write_png", "ptamd_write_png_top_down", "ptamd_sampling_rate_rgba8",
 )
 
@@ -26,7 +27,8 @@ class PtamdError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(_HERE, "libptamd.so")
+    """PTAMD_LIB selects another build of the same library (kernel A/B runs)."""
+    return os.environ.get("PTAMD_LIB") or os.path.join(_HERE, "libptamd.so")
 
 
 def lib():
@@ -63,6 +65,11 @@ def lib():
     L.ptamd_trace_pixels.argtypes = [vp, vp, i64, i32, i32, vp, vp]
     L.ptamd_adaptive_filter.argtypes = [vp, vp, i64, i32, vp, vp, vp, vp]
     L.ptamd_frame_resolve.argtypes = [vp, vp, vp, vp, vp]
+    pl = C.POINTER(PixelList)
+    L.ptamd_trace_list.argtypes = [vp, pl, i32, i32, vp, vp]
+    L.ptamd_filter_list.argtypes = [vp, pl, i32, vp, vp, vp, vp]
+    L.ptamd_pack_rows.argtypes = [vp, pl, vp, vp, vp]
+    L.ptamd_unpack_rows.argtypes = [vp, pl, i32, i32, vp, i64, vp, vp]
     L.ptamd_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.ptamd_tonemap_rgba8.argtypes = [pd, i32, i32, C.POINTER(C.c_uint32)]
     L.ptamd_write_png.argtypes = [C.c_char_p, C.POINTER(C.c_uint32), i32, i32]
@@ -169,6 +176,19 @@ class Device:
 
     def frame_resolve(self, d_state, d_hdr, d_count, stream=0):
         _check(lib().ptamd_frame_resolve(self._h, d_state, d_hdr, d_count, stream))
+
+    # the same on lists whose length lives on the device (cabi.PixelList)
+    def trace_list(self, plist, sample_base, n_samples, d_state, stream=0):
+        _check(lib().ptamd_trace_list(self._h, C.byref(plist), sample_base, n_samples, d_state, stream))
+
+    def filter_list(self, plist, n_done, d_state, d_out, d_n_out, stream=0):
+        _check(lib().ptamd_filter_list(self._h, C.byref(plist), n_done, d_state, d_out, d_n_out, stream))
+
+    def pack_rows(self, plist, d_state, d_rows, stream=0):
+        _check(lib().ptamd_pack_rows(self._h, C.byref(plist), d_state, d_rows, stream))
+
+    def unpack_rows(self, plist, world, skip_rank, d_rows, rows_per_rank, d_state, stream=0):
+        _check(lib().ptamd_unpack_rows(self._h, C.byref(plist), world, skip_rank, d_rows, rows_per_rank, d_state, stream))
 
     def stats(self):
         st = Stats()

@@ -38,6 +38,13 @@ class RenderParams(C.Structure):
                 ("hemisphere", C.c_int32), ("max_tolerance", C.c_double), ("seed", C.c_uint64)]
 
 
+class PixelList(C.Structure):
+    """ptamd_pixel_list: a shard (offset, stride) of a device-resident pixel list whose
+    length is read on the device from d_n (or is n when d_n is 0); n_max bounds it."""
+    _fields_ = [("d_pixels", C.c_void_p), ("d_n", C.c_void_p), ("n", C.c_int64), ("n_max", C.c_int64),
+                ("offset", C.c_int32), ("stride", C.c_int32)]
+
+
 class Stats(C.Structure):
     _fields_ = [("seconds", C.c_double), ("samples", C.c_uint64), ("rays", C.c_uint64),
                 ("shadow_rays", C.c_uint64), ("path_vertices", C.c_uint64),

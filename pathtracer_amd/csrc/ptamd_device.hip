@@ -90,10 +90,24 @@ struct FrameParams {
 };
 
 struct Ctl {
-  uint32_t n_cur, n_next, n_shadow, pad;
-  uint32_t grab_extend, grab_shadow, pad2[2];  // next unclaimed ray of the running traversal kernel
-  unsigned long long st_rays, st_shadow, st_vertices, st_nodes, st_tests;
-  long long filt_count;
+  uint32_t n_cur, n_next, n_shadow, n_pix;  // sizes of the ray lists; pixels of the running chunk
+  unsigned long long st_rays, st_shadow, st_vertices, st_nodes, st_tests, st_samples;
+};
+
+// A shard of a device-resident pixel list: entries offset, offset + stride, ...
+// below the list's length, which is read on the device when d_n is given (the
+// host then only knows an upper bound).
+struct PixView {
+  const int32_t *pixels;
+  const long long *d_n;
+  long long n;
+  uint32_t offset, stride;
+  __device__ __forceinline__ long long total() const { return d_n ? *d_n : n; }
+  __device__ __forceinline__ uint32_t count() const {
+    const long long t = total();
+    return t > (long long)offset ? (uint32_t)((t - offset + stride - 1) / stride) : 0u;
+  }
+  __device__ __forceinline__ int32_t at(uint32_t k) const { return pixels[offset + (size_t)k * stride]; }
 };
 
 // Ray queue entry arrays (SoA, capacity = max paths)
@@ -172,7 +186,25 @@ __device__ __forceinline__ bool slab_f(const float lo[3], const float hi[3], con
 // Per-lane traversal stack: the first STACK_LDS levels live in LDS (entry
 // (level, lane) at lds[level * blockDim.x + tid], conflict-free for any mix of
 // levels), deeper levels spill to a per-thread strip of global memory.
-constexpr int STACK_LDS = 12;
+#ifndef PTAMD_STACK_LDS
+#define PTAMD_STACK_LDS 10
+#endif
+constexpr int STACK_LDS = PTAMD_STACK_LDS;
+// Build-time tuning of the traversal kernels (defaults are the measured best):
+// resident waves per SIMD the register allocator must make room for (0: its own
+// choice; 6 costs a few spilled registers and still wins, 7 loses, 8 does not
+// compile), workgroups launched per resident workgroup slot.
+#ifndef PTAMD_WAVES_PER_EU
+#define PTAMD_WAVES_PER_EU 6
+#endif
+#ifndef PTAMD_GRID_MULT
+#define PTAMD_GRID_MULT 4
+#endif
+#if PTAMD_WAVES_PER_EU > 0
+#define TRAV_BOUNDS __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PTAMD_WAVES_PER_EU, PTAMD_WAVES_PER_EU)))
+#else
+#define TRAV_BOUNDS __launch_bounds__(256)
+#endif
 struct TravStack {
   uint2 *lds;
   uint2 *glob;
@@ -339,81 +371,27 @@ struct Walk {
   }
 };
 
-// Traces a list of rays. Policy: load(i, o, d, min_t, max_t) reads ray i;
-// store(i, hit, found) writes its result.
+// Traces a list of rays, one ray per lane per grid-stride step. Policy:
+// load(i, o, d, min_t, max_t) reads ray i; store(i, hit, found) writes its result.
 //
-// PERSISTENT = false: one ray per lane per grid-stride step.
-// PERSISTENT = true: a wave claims chunks of the list and every lane fetches the
-// next ray as soon as its own is finished; lanes that hold a primitive wait until
-// enough of them do, so the FP64 test runs on a fuller wave.
-template <bool ANY, bool COUNT, bool PERSISTENT, class Policy>
-__device__ __forceinline__ void trace_rays(const DevScene &S, const Policy &pol, uint32_t n, uint32_t *grab,
-                                           const TravStack &stack, uint32_t &n_nodes, uint32_t &n_tests) {
+// (A persistent-wave driver that refilled finished lanes from a shared counter
+// and batched primitive tests was measured too: 1.3x to 1.6x slower on MI355X,
+// the refilled lanes' rays being out of step with their neighbours.)
+template <bool ANY, bool COUNT, class Policy>
+__device__ __forceinline__ void trace_rays(const DevScene &S, const Policy &pol, uint32_t n, const TravStack &stack,
+                                           uint32_t &n_nodes, uint32_t &n_tests) {
   Walk w;
-  if (!PERSISTENT) {
-    const uint32_t stride = gridDim.x * blockDim.x;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-      v3 o, d;
-      double tmin, tmax;
-      pol.load(i, o, d, tmin, tmax);
-      w.begin(S, o, d, tmin, tmax);
-      while (w.cur != CHILD_EMPTY) {
-        if (w.cur >= 0) w.template node_step<COUNT>(S, stack, n_nodes);
-        else if (w.template prim_step<ANY, COUNT>(S, stack, n_tests)) break;
-      }
-      pol.store(i, w.hit, w.hit.prim >= 0);
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    v3 o, d;
+    double tmin, tmax;
+    pol.load(i, o, d, tmin, tmax);
+    w.begin(S, o, d, tmin, tmax);
+    while (w.cur != CHILD_EMPTY) {
+      if (w.cur >= 0) w.template node_step<COUNT>(S, stack, n_nodes);
+      else if (w.template prim_step<ANY, COUNT>(S, stack, n_tests)) break;
     }
-    return;
-  }
-  constexpr uint32_t GRAB = 256;
-  constexpr int PRIM_LANES = 20;
-  uint32_t next = 0, end = 0, idx = 0;
-  bool exhausted = false, active = false;
-  const int lane = threadIdx.x & 63;
-  const unsigned long long below = (1ull << lane) - 1ull;
-  w.begin(S, V(0, 0, 0), V(0, 0, 1), 0, 0);
-  w.cur = CHILD_EMPTY;
-  for (;;) {
-    const unsigned long long idle = __ballot(!active);
-    if (idle) {
-      if (next >= end && !exhausted) {
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(grab, GRAB);
-        base = __shfl(base, 0);
-        next = base;
-        end = base + GRAB < n ? base + GRAB : n;
-        if (base >= n) { exhausted = true; next = end = 0; }
-      }
-      if (next < end) {
-        const uint32_t mine = next + (uint32_t)__popcll(idle & below);
-        if (!active && mine < end) {
-          idx = mine;
-          v3 o, d;
-          double tmin, tmax;
-          pol.load(idx, o, d, tmin, tmax);
-          w.begin(S, o, d, tmin, tmax);
-          active = true;
-        }
-        const uint32_t taken = (uint32_t)__popcll(idle);
-        next = next + taken < end ? next + taken : end;
-      }
-    }
-    if (!__ballot(active)) {
-      if (exhausted) break;
-      continue;
-    }
-    if (active && w.cur >= 0) w.template node_step<COUNT>(S, stack, n_nodes);
-    bool done = active && w.cur == CHILD_EMPTY;
-    const bool on_prim = active && w.cur < 0 && w.cur != CHILD_EMPTY;
-    const unsigned long long pm = __ballot(on_prim);
-    const unsigned long long nm = __ballot(active && w.cur >= 0);
-    if (pm && (__popcll(pm) >= PRIM_LANES || nm == 0)) {
-      if (on_prim) done = w.template prim_step<ANY, COUNT>(S, stack, n_tests);
-    }
-    if (done) {
-      pol.store(idx, w.hit, w.hit.prim >= 0);
-      active = false;
-    }
+    pol.store(i, w.hit, w.hit.prim >= 0);
   }
 }
 
@@ -500,12 +478,15 @@ __device__ __forceinline__ v3 light_sample_L(const DevScene &S, int li, v3 p, do
 }
 
 // ------------------------------------------------------------------ kernels
-__global__ void k_set_counts(Ctl *ctl, uint32_t n_cur) {
-  ctl->grab_extend = 0;
-  ctl->grab_shadow = 0;
-  ctl->n_cur = n_cur;
+// Start of a chunk: pixels [p0, p0 + chunk) of the shard, ns paths each.
+__global__ void k_set_counts(Ctl *ctl, PixView pv, uint32_t p0, uint32_t chunk, uint32_t ns) {
+  const uint32_t have = pv.count();
+  const uint32_t np = have > p0 ? (have - p0 < chunk ? have - p0 : chunk) : 0u;
+  ctl->n_pix = np;
+  ctl->n_cur = np * ns;
   ctl->n_next = 0;
   ctl->n_shadow = 0;
+  ctl->st_samples += (unsigned long long)np * ns;
 }
 
 // end of one depth: fold the stage's counts into the statistics, make the next
@@ -517,8 +498,6 @@ __global__ void k_advance(Ctl *ctl, int count_vertices) {
   ctl->n_cur = ctl->n_next;
   ctl->n_next = 0;
   ctl->n_shadow = 0;
-  ctl->grab_extend = 0;
-  ctl->grab_shadow = 0;
 }
 
 // Camera::generate_ray, src/pathtracer/camera.cpp:190-203
@@ -532,11 +511,12 @@ __device__ __forceinline__ void camera_ray(const FrameParams &fp, double x, doub
 // One thread per path of the round: pixel = pixels[k / ns], sample = base + k % ns.
 // raytrace_pixel's ray set-up, src/pathtracer/pathtracer.cpp:259-261, with
 // JitteredSampler2D::get_sample (src/pathtracer/sampler.cpp:14-18).
-__global__ void k_generate(FrameParams fp, DevScene S, const int32_t *__restrict__ pixels, uint32_t n_paths,
-                           int32_t sample_base, int32_t ns, RayQ q, PathBuf pb) {
+__global__ void k_generate(FrameParams fp, DevScene S, PixView pv, uint32_t p0, const Ctl *ctl, int32_t sample_base,
+                           int32_t ns, RayQ q, PathBuf pb) {
   const uint32_t stride = gridDim.x * blockDim.x;
+  const uint32_t n_paths = ctl->n_cur;
   for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n_paths; k += stride) {
-    const int32_t pix = pixels[k / (uint32_t)ns];
+    const int32_t pix = pv.at(p0 + k / (uint32_t)ns);
     const int32_t s = sample_base + (int32_t)(k % (uint32_t)ns);
     const int32_t x = pix % fp.w, y = pix / fp.w;
     uint32_t wd[4];
@@ -594,15 +574,15 @@ struct ExtendPolicy {
   }
 };
 
-template <bool COUNT, bool PERSISTENT>
-__global__ void __launch_bounds__(256)
+template <bool COUNT>
+__global__ void TRAV_BOUNDS
     k_extend(DevScene S, RayQ q, const int32_t *__restrict__ list, HitBuf hb, Ctl *ctl, double min_t, double max_t,
              uint2 *gstack) {
   extern __shared__ uint2 lds_stack[];
   const TravStack stack{lds_stack, gstack, gridDim.x * blockDim.x, blockIdx.x * blockDim.x + threadIdx.x};
   uint32_t cn = 0, ct = 0;
   const ExtendPolicy pol{q, list, hb, min_t, max_t};
-  trace_rays<false, COUNT, PERSISTENT>(S, pol, ctl->n_cur, &ctl->grab_extend, stack, cn, ct);
+  trace_rays<false, COUNT>(S, pol, ctl->n_cur, stack, cn, ct);
   if (COUNT) {
     atomicAdd(&ctl->st_nodes, (unsigned long long)cn);
     atomicAdd(&ctl->st_tests, (unsigned long long)ct);
@@ -645,15 +625,15 @@ struct ShadowPolicy {
   }
 };
 
-template <bool HEMI, bool COUNT, bool PERSISTENT>
-__global__ void __launch_bounds__(256)
+template <bool HEMI, bool COUNT>
+__global__ void TRAV_BOUNDS
     k_shadow(DevScene S, ShadowQ sq, VertexBuf vb, Ctl *ctl, int32_t nls, uint2 *gstack) {
   extern __shared__ uint2 lds_stack[];
   const TravStack stack{lds_stack, gstack, gridDim.x * blockDim.x, blockIdx.x * blockDim.x + threadIdx.x};
   uint32_t cn = 0, ct = 0;
   const ShadowPolicy<HEMI> pol{S, sq, vb, (uint32_t)nls};
-  if (HEMI) trace_rays<false, COUNT, PERSISTENT>(S, pol, ctl->n_shadow, &ctl->grab_shadow, stack, cn, ct);
-  else trace_rays<true, COUNT, PERSISTENT>(S, pol, ctl->n_shadow, &ctl->grab_shadow, stack, cn, ct);
+  if (HEMI) trace_rays<false, COUNT>(S, pol, ctl->n_shadow, stack, cn, ct);
+  else trace_rays<true, COUNT>(S, pol, ctl->n_shadow, stack, cn, ct);
   if (COUNT) {
     atomicAdd(&ctl->st_nodes, (unsigned long long)cn);
     atomicAdd(&ctl->st_tests, (unsigned long long)ct);
@@ -672,7 +652,7 @@ struct Compact {
 // T * direct light.
 __global__ void __launch_bounds__(256)
     k_shade(FrameParams fp, DevScene S, RayQ q, const int32_t *__restrict__ list, HitBuf hb, RayQ qn, ShadowQ sq,
-            VertexBuf vb, PathBuf pb, Compact cp, Ctl *ctl, int32_t depth, const int32_t *__restrict__ pixels,
+            VertexBuf vb, PathBuf pb, Compact cp, Ctl *ctl, int32_t depth, PixView pv, uint32_t p0,
             int32_t sample_base, int32_t ns) {
   __shared__ uint32_t wsum[2][4];
   const uint32_t n = ctl->n_cur;
@@ -746,7 +726,7 @@ __global__ void __launch_bounds__(256)
             f = vdivs(V(S.mat_param[3 * mat], S.mat_param[3 * mat + 1], S.mat_param[3 * mat + 2]), PT_PI);
           // the path's random numbers: key (seed, pixel), counter (sample, block)
           const uint32_t k = (uint32_t)path;
-          rng_pix = (uint32_t)pixels[k / (uint32_t)ns];
+          rng_pix = (uint32_t)pv.at(p0 + k / (uint32_t)ns);
           rng_s = (uint32_t)(sample_base + (int32_t)(k % (uint32_t)ns));
           rng_base = 1u + (uint32_t)(depth - 1) * (uint32_t)fp.bpv;
           uint32_t wd[4];
@@ -958,11 +938,12 @@ __device__ __forceinline__ float illum(v3 v) { return (float)(0.2126f * v.x + 0.
 
 // Folds the round's finished paths into the per-pixel sums, in sample order
 // (pathtracer.cpp:262-266). state: [pixel*6] = s1, s2, sum.rgb, n.
-__global__ void k_accumulate(const int32_t *__restrict__ pixels, uint32_t n_pixels, int32_t ns, PathBuf pb,
+__global__ void k_accumulate(PixView pv, uint32_t p0, const Ctl *ctl, int32_t ns, PathBuf pb,
                              double *__restrict__ state) {
   const uint32_t stride = gridDim.x * blockDim.x;
+  const uint32_t n_pixels = ctl->n_pix;
   for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n_pixels; p += stride) {
-    double *st = state + (size_t)pixels[p] * 6;
+    double *st = state + (size_t)pv.at(p0 + p) * 6;
     double s1 = st[0], s2 = st[1];
     v3 sum = V(st[2], st[3], st[4]);
     const size_t b = (size_t)p * (uint32_t)ns;
@@ -990,11 +971,12 @@ __device__ __forceinline__ bool pixel_continues(const double *st, int32_t i, dou
 
 // Ordered stream compaction of the still-active pixels, three small kernels:
 // per-block counts, scan of the counts, scatter.
-__global__ void k_filter_count(const int32_t *__restrict__ pixels, uint32_t n, int32_t n_done, double tol,
-                               const double *__restrict__ state, uint32_t *__restrict__ block_count) {
+__global__ void k_filter_count(PixView pv, int32_t n_done, double tol, const double *__restrict__ state,
+                               uint32_t *__restrict__ block_count) {
   __shared__ uint32_t wave_cnt[4];
+  const uint32_t n = pv.count();
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool keep = i < n && pixel_continues(state + (size_t)pixels[i] * 6, n_done, tol);
+  const bool keep = i < n && pixel_continues(state + (size_t)pv.at(i) * 6, n_done, tol);
   const unsigned long long m = __ballot(keep);
   if (__lane_id() == 0) wave_cnt[threadIdx.x >> 6] = (uint32_t)__popcll(m);
   __syncthreads();
@@ -1024,19 +1006,19 @@ __global__ void k_filter_scan(uint32_t *block_count, uint32_t n_blocks, long lon
   }
   if (threadIdx.x == 0) *total_out = (long long)carry;
 }
-__global__ void k_filter_scatter(const int32_t *__restrict__ pixels, uint32_t n, int32_t n_done, double tol,
-                                 const double *__restrict__ state, const uint32_t *__restrict__ block_offset,
-                                 int32_t *__restrict__ out) {
+__global__ void k_filter_scatter(PixView pv, int32_t n_done, double tol, const double *__restrict__ state,
+                                 const uint32_t *__restrict__ block_offset, int32_t *__restrict__ out) {
   __shared__ uint32_t wave_cnt[4];
+  const uint32_t n = pv.count();
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool keep = i < n && pixel_continues(state + (size_t)pixels[i] * 6, n_done, tol);
+  const bool keep = i < n && pixel_continues(state + (size_t)pv.at(i) * 6, n_done, tol);
   const unsigned long long m = __ballot(keep);
   const int lane = __lane_id(), wv = threadIdx.x >> 6;
   if (lane == 0) wave_cnt[wv] = (uint32_t)__popcll(m);
   __syncthreads();
   uint32_t off = block_offset[blockIdx.x];
   for (int k = 0; k < wv; k++) off += wave_cnt[k];
-  if (keep) out[off + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = pixels[i];
+  if (keep) out[off + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = pv.at(i);
 }
 
 // pixel_sum / n and the sample count, pathtracer.cpp:268-271
@@ -1060,6 +1042,28 @@ __global__ void k_iota(int32_t *out, uint32_t n, int32_t w, int32_t x0, int32_t 
   const uint32_t stride = gridDim.x * blockDim.x;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
     out[i] = (y0 + (int32_t)(i / (uint32_t)rw)) * w + x0 + (int32_t)(i % (uint32_t)rw);
+}
+
+// State rows of a shard's pixels, gathered into a dense block (what a rank sends
+// after a round) and scattered back from the blocks of all ranks: entry i of the
+// whole list was traced by rank i % world and is row i / world of its block.
+__global__ void k_pack_rows(PixView pv, const double *__restrict__ state, double *__restrict__ rows) {
+  const uint32_t n = pv.count();
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n * 6u; t += stride) {
+    const uint32_t k = t / 6u, f = t % 6u;
+    rows[t] = state[(size_t)pv.at(k) * 6 + f];
+  }
+}
+__global__ void k_unpack_rows(PixView pv, uint32_t world, uint32_t skip_rank, const double *__restrict__ rows, uint32_t m,
+                              double *__restrict__ state) {
+  const uint32_t n = pv.count();
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n * 6u; t += stride) {
+    const uint32_t i = t / 6u, f = t % 6u;
+    const uint32_t r = i % world, k = i / world;
+    if (r != skip_rank) state[(size_t)pv.at(i) * 6 + f] = rows[((size_t)r * m + k) * 6 + f];
+  }
 }
 
 }  // namespace
@@ -1110,6 +1114,13 @@ struct ptamd_context {
   bool prof_events = false, prof_counters = false;
   struct Ev { int cls; hipEvent_t a, b; };
   std::vector<Ev> events;
+  std::vector<hipEvent_t> event_pool;  // recycled: creating an event per launch costs more than the launch
+  hipEvent_t take_event() {
+    hipEvent_t e = nullptr;
+    if (!event_pool.empty()) { e = event_pool.back(); event_pool.pop_back(); }
+    else (void)hipEventCreate(&e);
+    return e;
+  }
   ptamd_stats stats{};
 };
 
@@ -1148,8 +1159,8 @@ struct Launcher {
     if (c->prof_events) {
       ptamd_context::Ev e;
       e.cls = cls;
-      (void)hipEventCreate(&e.a);
-      (void)hipEventCreate(&e.b);
+      e.a = c->take_event();
+      e.b = c->take_event();
       (void)hipEventRecord(e.a, s);
       c->events.push_back(e);
     }
@@ -1163,8 +1174,8 @@ void collect_events(ptamd_context *c) {
   for (auto &e : c->events) {
     float ms = 0;
     if (hipEventSynchronize(e.b) == hipSuccess && hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) c->stats.kernel_ms[e.cls] += ms;
-    (void)hipEventDestroy(e.a);
-    (void)hipEventDestroy(e.b);
+    c->event_pool.push_back(e.a);
+    c->event_pool.push_back(e.b);
   }
   c->events.clear();
 }
@@ -1300,6 +1311,7 @@ void ptamd_destroy(ptamd_context *c) {
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
   collect_events(c);
+  for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
   free_scene(c);
   if (c->slab) (void)hipFree(c->slab);
   if (c->block_count) (void)hipFree(c->block_count);
@@ -1601,10 +1613,6 @@ int ptamd_frame_begin(ptamd_context *c, const ptamd_render_params *p) {
 
 // Launch shape of the traversal kernels: 256-thread workgroups, STACK_LDS stack
 // levels per lane in LDS, the rest (if the tree is deeper) in a global strip.
-// false: one ray per lane per grid-stride step; true: persistent waves that refill
-// idle lanes (see trace_rays). Measured on MI355X; the simple form wins.
-constexpr bool PERSIST = false;
-
 struct TravLaunch {
   int block, grid;
   size_t lds;
@@ -1616,10 +1624,10 @@ static int traversal_launch(ptamd_context *c, TravLaunch *t) {
   // resident workgroups per CU: bounded by LDS (160 KiB per CU) and by registers
   // (about 5 waves per SIMD). The waves are persistent, so the grid is exactly
   // the resident set
-  const int wg_per_cu = std::max(1, std::min<int>((int)((160 * 1024) / std::max<size_t>(t->lds, 1)), 5));
-  // persistent waves: exactly the resident set; grid-stride: twice that, so a CU
-  // always has a workgroup to start when one drains
-  t->grid = c->num_cu * wg_per_cu * (PERSIST ? 1 : 2);
+  const int reg_waves = PTAMD_WAVES_PER_EU > 0 ? PTAMD_WAVES_PER_EU : 5;
+  const int wg_per_cu = std::max(1, std::min<int>((int)((160 * 1024) / std::max<size_t>(t->lds, 1)), reg_waves));
+  // a few workgroups per resident slot, so a CU always has one to start when one drains
+  t->grid = c->num_cu * wg_per_cu * PTAMD_GRID_MULT;
   const size_t levels = (size_t)std::max(0, c->S.stack_cap - STACK_LDS);
   const size_t need = levels * (size_t)t->grid * t->block * sizeof(uint2);
   if (need > c->gstack_bytes) {
@@ -1631,11 +1639,32 @@ static int traversal_launch(ptamd_context *c, TravLaunch *t) {
   return PTAMD_OK;
 }
 
-int ptamd_trace_pixels(ptamd_context *c, const int32_t *d_pixels, int64_t n, int32_t sample_base, int32_t n_samples,
-                       double *d_state, void *stream) {
+namespace {
+int check_list(const ptamd_pixel_list *l, const char *who) {
+  if (!l || l->n_max < 0 || l->stride < 1 || l->offset < 0 || (!l->d_n && (l->n < 0 || l->n > l->n_max)) ||
+      (l->n_max > 0 && !l->d_pixels) || l->n_max > (int64_t)0x7fffffff) {
+    ptamd::set_error(std::string("invalid pixel list passed to ") + who);
+    return PTAMD_ERR_ARG;
+  }
+  return PTAMD_OK;
+}
+PixView view_of(const ptamd_pixel_list *l) {
+  return PixView{l->d_pixels, (const long long *)l->d_n, (long long)l->n, (uint32_t)l->offset, (uint32_t)l->stride};
+}
+// entries of the shard, at most
+int64_t shard_max(const ptamd_pixel_list *l) {
+  return l->n_max > l->offset ? (l->n_max - l->offset + l->stride - 1) / l->stride : 0;
+}
+}  // namespace
+
+int ptamd_trace_list(ptamd_context *c, const ptamd_pixel_list *list, int32_t sample_base, int32_t n_samples,
+                     double *d_state, void *stream) {
   if (!c || !c->have_frame) { ptamd::set_error("ptamd_frame_begin must be called first"); return PTAMD_ERR_STATE; }
-  if (n < 0 || n_samples <= 0 || sample_base < 0 || (n > 0 && (!d_pixels || !d_state))) {
-    ptamd::set_error("invalid arguments to ptamd_trace_pixels");
+  int rc = check_list(list, "ptamd_trace_list");
+  if (rc) return rc;
+  const int64_t n = shard_max(list);
+  if (n_samples <= 0 || sample_base < 0 || (n > 0 && !d_state)) {
+    ptamd::set_error("invalid arguments to ptamd_trace_list");
     return PTAMD_ERR_ARG;
   }
   if (n == 0) return PTAMD_OK;
@@ -1645,7 +1674,7 @@ int ptamd_trace_pixels(ptamd_context *c, const int32_t *d_pixels, int64_t n, int
   const int nls = std::max(fp.nls, 1);
   int64_t px_per_chunk = std::max<int64_t>(1, c->max_paths / n_samples);
   px_per_chunk = std::min(px_per_chunk, n);
-  int rc = ensure_buffers(c, px_per_chunk * n_samples, nls, !fp.accum);
+  rc = ensure_buffers(c, px_per_chunk * n_samples, nls, !fp.accum);
   if (rc) return rc;
   TravLaunch tl;
   rc = traversal_launch(c, &tl);
@@ -1656,17 +1685,14 @@ int ptamd_trace_pixels(ptamd_context *c, const int32_t *d_pixels, int64_t n, int
   const int ggrid = grid_for(c, 8);
   PathBuf pb = c->pb;
   if (fp.accum) pb.pend[0] = pb.pend[1] = pb.pend[2] = nullptr;
+  const PixView pv = view_of(list);
   Launcher L{c, s};
   const int depths = std::max(1, fp.max_ray_depth);
   for (int64_t p0 = 0; p0 < n; p0 += px_per_chunk) {
-    const int64_t np = std::min(px_per_chunk, n - p0);
-    const uint32_t n_paths = (uint32_t)(np * n_samples);
-    const int32_t *pix = d_pixels + p0;
-    L.begin(PTAMD_K_OTHER);
-    hipLaunchKernelGGL(k_set_counts, 1, 1, 0, s, c->ctl, n_paths);
-    L.end();
+    const uint32_t up0 = (uint32_t)p0;
     L.begin(PTAMD_K_GENERATE);
-    hipLaunchKernelGGL(k_generate, ggrid, 256, 0, s, fp, c->S, pix, n_paths, sample_base, n_samples, c->q[0], pb);
+    hipLaunchKernelGGL(k_set_counts, 1, 1, 0, s, c->ctl, pv, up0, (uint32_t)px_per_chunk, (uint32_t)n_samples);
+    hipLaunchKernelGGL(k_generate, ggrid, 256, 0, s, fp, c->S, pv, up0, c->ctl, sample_base, n_samples, c->q[0], pb);
     L.end();
     int cur = 0;
     for (int depth = 1; depth <= depths; depth++) {
@@ -1674,12 +1700,12 @@ int ptamd_trace_pixels(ptamd_context *c, const int32_t *d_pixels, int64_t n, int
       const double max_t = depth == 1 ? fp.f_clip : (double)INFINITY;
       const int32_t *lst = depth == 1 ? nullptr : c->list[cur];
       L.begin(PTAMD_K_EXTEND);
-      if (c->prof_counters) hipLaunchKernelGGL((k_extend<true, PERSIST>), tgrid, tblock, lds, s, c->S, c->q[cur], lst, c->hb, c->ctl, min_t, max_t, gstack);
-      else hipLaunchKernelGGL((k_extend<false, PERSIST>), tgrid, tblock, lds, s, c->S, c->q[cur], lst, c->hb, c->ctl, min_t, max_t, gstack);
+      if (c->prof_counters) hipLaunchKernelGGL((k_extend<true>), tgrid, tblock, lds, s, c->S, c->q[cur], lst, c->hb, c->ctl, min_t, max_t, gstack);
+      else hipLaunchKernelGGL((k_extend<false>), tgrid, tblock, lds, s, c->S, c->q[cur], lst, c->hb, c->ctl, min_t, max_t, gstack);
       L.end();
       L.begin(PTAMD_K_SHADE);
       hipLaunchKernelGGL(k_shade, ggrid, 256, 0, s, fp, c->S, c->q[cur], lst, c->hb, c->q[cur ^ 1], c->sq, c->vb, pb, c->cp,
-                         c->ctl, depth, pix, sample_base, n_samples);
+                         c->ctl, depth, pv, up0, sample_base, n_samples);
       L.end();
       L.begin(PTAMD_K_OTHER);
       hipLaunchKernelGGL(k_scan2, 1, 1024, 0, s, c->cp, c->ctl);
@@ -1688,36 +1714,47 @@ int ptamd_trace_pixels(ptamd_context *c, const int32_t *d_pixels, int64_t n, int
       if (fp.max_ray_depth > 0 && fp.nls > 0) {
         L.begin(PTAMD_K_SHADOW);
         if (fp.hemisphere) {
-          if (c->prof_counters) hipLaunchKernelGGL((k_shadow<true, true, PERSIST>), tgrid, tblock, lds, s, c->S, c->sq, c->vb, c->ctl, nls, gstack);
-          else hipLaunchKernelGGL((k_shadow<true, false, PERSIST>), tgrid, tblock, lds, s, c->S, c->sq, c->vb, c->ctl, nls, gstack);
+          if (c->prof_counters) hipLaunchKernelGGL((k_shadow<true, true>), tgrid, tblock, lds, s, c->S, c->sq, c->vb, c->ctl, nls, gstack);
+          else hipLaunchKernelGGL((k_shadow<true, false>), tgrid, tblock, lds, s, c->S, c->sq, c->vb, c->ctl, nls, gstack);
         } else {
-          if (c->prof_counters) hipLaunchKernelGGL((k_shadow<false, true, PERSIST>), tgrid, tblock, lds, s, c->S, c->sq, c->vb, c->ctl, nls, gstack);
-          else hipLaunchKernelGGL((k_shadow<false, false, PERSIST>), tgrid, tblock, lds, s, c->S, c->sq, c->vb, c->ctl, nls, gstack);
+          if (c->prof_counters) hipLaunchKernelGGL((k_shadow<false, true>), tgrid, tblock, lds, s, c->S, c->sq, c->vb, c->ctl, nls, gstack);
+          else hipLaunchKernelGGL((k_shadow<false, false>), tgrid, tblock, lds, s, c->S, c->sq, c->vb, c->ctl, nls, gstack);
         }
         L.end();
         L.begin(PTAMD_K_RESOLVE);
         hipLaunchKernelGGL(k_resolve, ggrid, 256, 0, s, fp, c->q[cur], lst, c->vb, pb, c->ctl, depth);
+        hipLaunchKernelGGL(k_advance, 1, 1, 0, s, c->ctl, 1);
+        L.end();
+      } else {
+        L.begin(PTAMD_K_OTHER);
+        hipLaunchKernelGGL(k_advance, 1, 1, 0, s, c->ctl, 1);
         L.end();
       }
-      L.begin(PTAMD_K_OTHER);
-      hipLaunchKernelGGL(k_advance, 1, 1, 0, s, c->ctl, 1);
-      L.end();
       cur ^= 1;
     }
     L.begin(PTAMD_K_ACCUMULATE);
-    hipLaunchKernelGGL(k_accumulate, ggrid, 256, 0, s, pix, (uint32_t)np, n_samples, pb, d_state);
+    hipLaunchKernelGGL(k_accumulate, ggrid, 256, 0, s, pv, up0, c->ctl, n_samples, pb, d_state);
     L.end();
   }
   HIPCHK(hipGetLastError());
-  c->stats.samples += (uint64_t)n * (uint64_t)n_samples;
   return PTAMD_OK;
 }
 
-int ptamd_adaptive_filter(ptamd_context *c, const int32_t *d_in, int64_t n, int32_t n_done, const double *d_state,
-                          int32_t *d_out, int64_t *d_n_out, void *stream) {
+int ptamd_trace_pixels(ptamd_context *c, const int32_t *d_pixels, int64_t n, int32_t sample_base, int32_t n_samples,
+                       double *d_state, void *stream) {
+  if (n < 0 || (n > 0 && !d_pixels)) { ptamd::set_error("invalid arguments to ptamd_trace_pixels"); return PTAMD_ERR_ARG; }
+  const ptamd_pixel_list l{d_pixels, nullptr, n, n, 0, 1};
+  return ptamd_trace_list(c, &l, sample_base, n_samples, d_state, stream);
+}
+
+int ptamd_filter_list(ptamd_context *c, const ptamd_pixel_list *in, int32_t n_done, const double *d_state,
+                      int32_t *d_out, int64_t *d_n_out, void *stream) {
   if (!c || !c->have_frame) { ptamd::set_error("ptamd_frame_begin must be called first"); return PTAMD_ERR_STATE; }
-  if (n < 0 || n_done < 2 || !d_n_out || (n > 0 && (!d_in || !d_out || !d_state))) {
-    ptamd::set_error("invalid arguments to ptamd_adaptive_filter");
+  int rc = check_list(in, "ptamd_filter_list");
+  if (rc) return rc;
+  const int64_t n = shard_max(in);
+  if (n_done < 2 || !d_n_out || (n > 0 && (!d_out || !d_state))) {
+    ptamd::set_error("invalid arguments to ptamd_filter_list");
     return PTAMD_ERR_ARG;
   }
   HIPCHK(hipSetDevice(c->device));
@@ -1728,11 +1765,55 @@ int ptamd_adaptive_filter(ptamd_context *c, const int32_t *d_in, int64_t n, int3
     c->block_count_cap = std::max<size_t>(nb, 4096);
     HIPCHK(hipMalloc((void **)&c->block_count, c->block_count_cap * sizeof(uint32_t)));
   }
+  const PixView pv = view_of(in);
   Launcher L{c, s};
   L.begin(PTAMD_K_FILTER);
-  if (nb) hipLaunchKernelGGL(k_filter_count, nb, 256, 0, s, d_in, (uint32_t)n, n_done, c->params.max_tolerance, d_state, c->block_count);
+  if (nb) hipLaunchKernelGGL(k_filter_count, nb, 256, 0, s, pv, n_done, c->params.max_tolerance, d_state, c->block_count);
   hipLaunchKernelGGL(k_filter_scan, 1, 1024, 0, s, c->block_count, nb, (long long *)d_n_out);
-  if (nb) hipLaunchKernelGGL(k_filter_scatter, nb, 256, 0, s, d_in, (uint32_t)n, n_done, c->params.max_tolerance, d_state, c->block_count, d_out);
+  if (nb) hipLaunchKernelGGL(k_filter_scatter, nb, 256, 0, s, pv, n_done, c->params.max_tolerance, d_state, c->block_count, d_out);
+  L.end();
+  HIPCHK(hipGetLastError());
+  return PTAMD_OK;
+}
+
+int ptamd_adaptive_filter(ptamd_context *c, const int32_t *d_in, int64_t n, int32_t n_done, const double *d_state,
+                          int32_t *d_out, int64_t *d_n_out, void *stream) {
+  if (n < 0 || (n > 0 && !d_in)) { ptamd::set_error("invalid arguments to ptamd_adaptive_filter"); return PTAMD_ERR_ARG; }
+  const ptamd_pixel_list l{d_in, nullptr, n, n, 0, 1};
+  return ptamd_filter_list(c, &l, n_done, d_state, d_out, d_n_out, stream);
+}
+
+int ptamd_pack_rows(ptamd_context *c, const ptamd_pixel_list *list, const double *d_state, double *d_rows, void *stream) {
+  if (!c) { ptamd::set_error("null context"); return PTAMD_ERR_ARG; }
+  int rc = check_list(list, "ptamd_pack_rows");
+  if (rc) return rc;
+  if (shard_max(list) == 0) return PTAMD_OK;
+  if (!d_state || !d_rows) { ptamd::set_error("null buffer"); return PTAMD_ERR_ARG; }
+  HIPCHK(hipSetDevice(c->device));
+  Launcher L{c, (hipStream_t)stream};
+  L.begin(PTAMD_K_OTHER);
+  hipLaunchKernelGGL(k_pack_rows, grid_for(c, 4), 256, 0, (hipStream_t)stream, view_of(list), d_state, d_rows);
+  L.end();
+  HIPCHK(hipGetLastError());
+  return PTAMD_OK;
+}
+
+int ptamd_unpack_rows(ptamd_context *c, const ptamd_pixel_list *list, int32_t world, int32_t skip_rank,
+                      const double *d_rows, int64_t rows_per_rank, double *d_state, void *stream) {
+  if (!c) { ptamd::set_error("null context"); return PTAMD_ERR_ARG; }
+  int rc = check_list(list, "ptamd_unpack_rows");
+  if (rc) return rc;
+  if (world < 1 || list->offset != 0 || list->stride != 1 || rows_per_rank < (list->n_max + world - 1) / world) {
+    ptamd::set_error("invalid arguments to ptamd_unpack_rows");
+    return PTAMD_ERR_ARG;
+  }
+  if (list->n_max == 0) return PTAMD_OK;
+  if (!d_state || !d_rows) { ptamd::set_error("null buffer"); return PTAMD_ERR_ARG; }
+  HIPCHK(hipSetDevice(c->device));
+  Launcher L{c, (hipStream_t)stream};
+  L.begin(PTAMD_K_OTHER);
+  hipLaunchKernelGGL(k_unpack_rows, grid_for(c, 4), 256, 0, (hipStream_t)stream, view_of(list), (uint32_t)world,
+                     skip_rank < 0 ? 0xffffffffu : (uint32_t)skip_rank, d_rows, (uint32_t)rows_per_rank, d_state);
   L.end();
   HIPCHK(hipGetLastError());
   return PTAMD_OK;
@@ -1764,6 +1845,7 @@ int ptamd_get_stats(ptamd_context *c, ptamd_stats *out) {
     c->stats.path_vertices = h.st_vertices;
     c->stats.nodes_visited = h.st_nodes;
     c->stats.prim_tests = h.st_tests;
+    c->stats.samples = h.st_samples;
   }
   *out = c->stats;
   return PTAMD_OK;
@@ -1778,10 +1860,13 @@ int ptamd_render(ptamd_context *c, const ptamd_render_params *p, double *hdr_out
   const int64_t nrect = (x1 > x0 && y1 > y0) ? (int64_t)(x1 - x0) * (y1 - y0) : 0;
   double *d_state = nullptr, *d_hdr = nullptr;
   int32_t *d_list[2] = {nullptr, nullptr}, *d_count = nullptr;
-  long long *d_n = nullptr;
+  int64_t *d_n = nullptr, *h_n = nullptr;  // two list lengths on the device, their pinned host copies
+  hipEvent_t ev[2] = {nullptr, nullptr};
   auto cleanup = [&]() {
     (void)hipFree(d_state); (void)hipFree(d_hdr); (void)hipFree(d_list[0]); (void)hipFree(d_list[1]);
     (void)hipFree(d_count); (void)hipFree(d_n);
+    if (h_n) (void)hipHostFree(h_n);
+    for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
   };
 #define HIPCHK_CLEAN(expr)                                                              \
   do {                                                                                  \
@@ -1797,27 +1882,42 @@ int ptamd_render(ptamd_context *c, const ptamd_render_params *p, double *hdr_out
   HIPCHK_CLEAN(hipMalloc((void **)&d_count, npix * sizeof(int32_t)));
   HIPCHK_CLEAN(hipMalloc((void **)&d_list[0], std::max<int64_t>(nrect, 1) * sizeof(int32_t)));
   HIPCHK_CLEAN(hipMalloc((void **)&d_list[1], std::max<int64_t>(nrect, 1) * sizeof(int32_t)));
-  HIPCHK_CLEAN(hipMalloc((void **)&d_n, sizeof(long long)));
+  HIPCHK_CLEAN(hipMalloc((void **)&d_n, 2 * sizeof(int64_t)));
+  HIPCHK_CLEAN(hipHostMalloc((void **)&h_n, 2 * sizeof(int64_t), hipHostMallocDefault));
+  HIPCHK_CLEAN(hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
+  HIPCHK_CLEAN(hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
   hipStream_t s = c->own_stream;
   HIPCHK_CLEAN(hipMemsetAsync(d_state, 0, npix * 6 * sizeof(double), s));
   if (nrect) hipLaunchKernelGGL(k_iota, grid_for(c, 4), 256, 0, s, d_list[0], (uint32_t)nrect, p->w, x0, y0, x1 - x0);
+  {
+    const int64_t init[2] = {nrect, nrect};
+    HIPCHK_CLEAN(hipMemcpyAsync(d_n, init, sizeof init, hipMemcpyHostToDevice, s));
+  }
   HIPCHK_CLEAN(hipStreamSynchronize(s));
   auto t0 = std::chrono::steady_clock::now();
-  int64_t n = nrect;
+  // Round r traces the survivors of the adaptive test after round r - 1. Their
+  // number stays on the device; the host only needs an upper bound to size the
+  // launches, and uses the count of one round earlier, read back asynchronously,
+  // so the GPU never waits for the host between rounds.
+  int64_t n_known = nrect;
   int cur = 0, done = 0;
-  while (done < p->ns_aa && n > 0) {
-    if (done > 0) {
-      rc = ptamd_adaptive_filter(c, d_list[cur], n, done, d_state, d_list[cur ^ 1], (int64_t *)d_n, s);
+  for (int r = 0; done < p->ns_aa && n_known > 0; r++) {
+    ptamd_pixel_list l{d_list[cur], d_n + cur, 0, n_known, 0, 1};
+    if (r > 0) {
+      rc = ptamd_filter_list(c, &l, done, d_state, d_list[cur ^ 1], d_n + (cur ^ 1), s);
       if (rc) { cleanup(); return rc; }
-      long long hn = 0;
-      HIPCHK_CLEAN(hipMemcpyAsync(&hn, d_n, sizeof hn, hipMemcpyDeviceToHost, s));
-      HIPCHK_CLEAN(hipStreamSynchronize(s));
-      n = hn;
       cur ^= 1;
-      if (n == 0) break;
+      HIPCHK_CLEAN(hipMemcpyAsync(h_n + (r & 1), d_n + cur, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+      HIPCHK_CLEAN(hipEventRecord(ev[r & 1], s));
+      if (r > 1) {
+        HIPCHK_CLEAN(hipEventSynchronize(ev[(r - 1) & 1]));
+        n_known = h_n[(r - 1) & 1];
+        if (n_known == 0) break;
+      }
+      l = ptamd_pixel_list{d_list[cur], d_n + cur, 0, n_known, 0, 1};
     }
     const int ns = std::min(p->samples_per_batch, p->ns_aa - done);
-    rc = ptamd_trace_pixels(c, d_list[cur], n, done, ns, d_state, s);
+    rc = ptamd_trace_list(c, &l, done, ns, d_state, s);
     if (rc) { cleanup(); return rc; }
     done += ns;
   }
@@ -1856,9 +1956,9 @@ int ptamd_trace_primary(ptamd_context *c, int64_t n, const double *sx, const dou
     const int64_t m = std::min(chunk, n - b);
     HIPCHK(hipMemcpyAsync(d_sx, sx + b, m * sizeof(double), hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(d_sy, sy + b, m * sizeof(double), hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_set_counts, 1, 1, 0, s, c->ctl, (uint32_t)m);
+    hipLaunchKernelGGL(k_set_counts, 1, 1, 0, s, c->ctl, PixView{nullptr, nullptr, (long long)m, 0u, 1u}, 0u, (uint32_t)m, 1u);
     hipLaunchKernelGGL(k_generate_primary, grid_for(c, 4), 256, 0, s, c->fp, d_sx, d_sy, (uint32_t)m, c->q[0]);
-    hipLaunchKernelGGL((k_extend<false, PERSIST>), tgrid, tblock, lds, s, c->S, c->q[0], (const int32_t *)nullptr, c->hb, c->ctl, c->fp.n_clip, c->fp.f_clip, tl.gstack);
+    hipLaunchKernelGGL((k_extend<false>), tgrid, tblock, lds, s, c->S, c->q[0], (const int32_t *)nullptr, c->hb, c->ctl, c->fp.n_clip, c->fp.f_clip, tl.gstack);
     HIPCHK(hipMemcpyAsync(prim.data(), c->hb.prim, m * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(t_out + b, c->hb.t, m * sizeof(double), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));

@@ -14,6 +14,9 @@ replicates them, so every rank holds the whole frame state (s1, s2, sum, n per
 pixel) and computes the same next work list. The frame buffer is therefore
 assembled incrementally by RCCL and needs no final gather.
 
+Nothing in the loop waits for the GPU: the list lengths live in device memory
+and the kernels read them there (see render_frame).
+
 Results do not depend on the number of ranks: the random numbers of a path are
 keyed by (seed, pixel, sample) and a pixel's samples are summed in sample order.
 
@@ -25,7 +28,7 @@ import math
 import numpy as np
 import torch
 
-from . import api
+from . import api, cabi  # noqa: F401
 
 
 class PixelSchedule:
@@ -45,69 +48,79 @@ class PixelSchedule:
         return math.ceil(n_active / world) if n_active else 0
 
 
-def _exchange(state6, active, mine_idx, world, group):
-    """All-gather of the rows each rank updated; `state6` is [npix, 6]."""
-    import torch.distributed as dist
-    n = active.numel()
-    m = PixelSchedule.padded(n, world)
-    send = torch.zeros((m, 6), dtype=state6.dtype, device=state6.device)
-    k = mine_idx.numel()
-    if k:
-        send[:k] = state6.index_select(0, mine_idx.long())
-    # output = the ranks' blocks concatenated along dim 0 (the layout both RCCL and
-    # gloo accept for all_gather_into_tensor)
-    recv = torch.empty((world * m, 6), dtype=state6.dtype, device=state6.device)
-    dist.all_gather_into_tensor(recv, send, group=group)
-    recv = recv.view(world, m, 6)
-    # rank r's rows are active[r::world]
-    for r in range(world):
-        idx = active[r::world].long()
-        if idx.numel():
-            state6.index_copy_(0, idx, recv[r, :idx.numel()])
-
-
-def render_frame(dev, params, rank=0, world=1, group=None, device=None, record_rounds=None):
-    """Renders one frame; returns (hdr[h,w,3], count[h,w]) as CUDA tensors on every rank.
+def render_frame(dev, params, rank=0, world=1, group=None, device=None, record_rounds=None, lag=1):
+    """Renders one frame; returns (hdr[h,w,3], count[h,w]) as tensors on `device`, on every rank.
 
     dev: api.Device with scene and camera set. With world > 1 the default process
     group (or `group`) must be initialised with a backend that can move tensors on
     `device` ("nccl" for GPUs).
+
+    The number of still-active pixels stays on the device. To size launches and
+    the exchange the host only needs an upper bound, and uses the count of `lag`
+    rounds earlier (counts never grow), copied back asynchronously: with lag = 1
+    the host queues round r while the GPU still runs round r - 1, so the GPU never
+    idles between rounds. lag = 0 reads every count before using it. The bound is
+    the same on every rank (it is a count, not a timing), so the ranks' collectives
+    always agree in size. record_rounds, if a list, receives (samples_done,
+    bound, this rank's share of the bound) per round.
     """
+    import torch.distributed as dist
     w, h = params.w, params.h
     device = device or torch.device("cuda", torch.cuda.current_device())
-    stream = torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0
+    on_gpu = device.type == "cuda"
+    stream = torch.cuda.current_stream(device).cuda_stream if on_gpu else 0
     npix = w * h
     state = torch.zeros(npix * 6, dtype=torch.float64, device=device)
-    state6 = state.view(npix, 6)
     x0, y0 = max(0, params.x0), max(0, params.y0)
     x1, y1 = min(w, params.x1), min(h, params.y1)
     ys = torch.arange(y0, y1, device=device, dtype=torch.int32)
     xs = torch.arange(x0, x1, device=device, dtype=torch.int32)
     bufs = [(ys[:, None] * w + xs[None, :]).reshape(-1).contiguous(), None]
     bufs[1] = torch.empty_like(bufs[0])
-    cur, n = 0, bufs[0].numel()
-    n_out = torch.zeros(1, dtype=torch.int64, device=device)
+    n0 = bufs[0].numel()
+    n_dev = torch.full((2,), n0, dtype=torch.int64, device=device)  # lengths of bufs[0], bufs[1]
+    pending = []  # (event or None, host tensor) of counts not yet read
+    rows_send = rows_recv = None
+    if world > 1:
+        m0 = PixelSchedule.padded(n0, world)
+        rows_send = torch.zeros((m0, 6), dtype=torch.float64, device=device)
+        rows_recv = torch.empty((world * m0, 6), dtype=torch.float64, device=device)
     dev.frame_begin(params)
-    done = 0
-    while done < params.ns_aa and n > 0:
+    cur, done, bound = 0, 0, n0
+    while done < params.ns_aa and bound > 0:
         if done > 0:
             # the adaptive test of raytrace_pixel at i = done; every rank holds the
             # whole state, so every rank computes the same survivor list
-            dev.adaptive_filter(bufs[cur].data_ptr(), n, done, state.data_ptr(), bufs[cur ^ 1].data_ptr(),
-                                n_out.data_ptr(), stream)
-            n = int(n_out.item())
+            whole = cabi.PixelList(bufs[cur].data_ptr(), n_dev[cur:].data_ptr(), 0, bound, 0, 1)
+            dev.filter_list(whole, done, state.data_ptr(), bufs[cur ^ 1].data_ptr(), n_dev[cur ^ 1:].data_ptr(), stream)
             cur ^= 1
-            if n == 0:
+            host_n = torch.empty(1, dtype=torch.int64, pin_memory=on_gpu)
+            host_n.copy_(n_dev[cur:cur + 1], non_blocking=True)
+            ev = None
+            if on_gpu:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(device))
+            pending.append((ev, host_n))
+            while len(pending) > lag:
+                ev, t = pending.pop(0)
+                if ev is not None:
+                    ev.synchronize()
+                bound = min(bound, int(t.item()))
+            if bound == 0:
                 break
-        active = bufs[cur][:n]
         ns = min(params.samples_per_batch, params.ns_aa - done)
-        mine = active[rank::world].contiguous() if world > 1 else active
+        whole = cabi.PixelList(bufs[cur].data_ptr(), n_dev[cur:].data_ptr(), 0, bound, 0, 1)
+        mine = cabi.PixelList(bufs[cur].data_ptr(), n_dev[cur:].data_ptr(), 0, bound, rank, world)
         if record_rounds is not None:
-            record_rounds.append((done, n, int(mine.numel())))
-        if mine.numel():
-            dev.trace_pixels(mine.data_ptr(), mine.numel(), done, ns, state.data_ptr(), stream)
+            record_rounds.append((done, bound, PixelSchedule.shard_size(bound, rank, world)))
+        dev.trace_list(mine, done, ns, state.data_ptr(), stream)
         if world > 1:
-            _exchange(state6, active, mine, world, group)
+            # every rank's updated rows to every rank: pack, one all-gather, unpack
+            m = PixelSchedule.padded(bound, world)
+            send, recv = rows_send[:m], rows_recv[:world * m]
+            dev.pack_rows(mine, state.data_ptr(), send.data_ptr(), stream)
+            dist.all_gather_into_tensor(recv, send, group=group)
+            dev.unpack_rows(whole, world, rank, recv.data_ptr(), m, state.data_ptr(), stream)
         done += ns
     hdr = torch.empty(npix * 3, dtype=torch.float64, device=device)
     cnt = torch.empty(npix, dtype=torch.int32, device=device)

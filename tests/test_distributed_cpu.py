@@ -33,9 +33,17 @@ class OracleDevice:
         ct = {np.float64: C.c_double, np.int32: C.c_int32, np.int64: C.c_int64}[dtype]
         return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ct)), shape=(n,))
 
-    def trace_pixels(self, d_pixels, n, sample_base, n_samples, d_state, stream=0):
+    def _entries(self, pl):
+        """The shard's pixel indices, as the device kernels enumerate them."""
+        n = int(self._view(pl.d_n, 1, np.int64)[0]) if pl.d_n else int(pl.n)
+        assert 0 <= n <= pl.n_max, "the host's bound must cover the device-side length"
+        if n == 0:
+            return np.zeros(0, np.int32)
+        return self._view(pl.d_pixels, n, np.int32)[pl.offset::pl.stride].copy()
+
+    def trace_list(self, pl, sample_base, n_samples, d_state, stream=0):
         p = self.p
-        pix = self._view(d_pixels, n, np.int32)
+        pix = self._entries(pl)
         st = self._view(d_state, p.w * p.h * 6, np.float64).reshape(-1, 6)
         rgb = (C.c_double * 3)()
         for px in pix:
@@ -53,11 +61,11 @@ class OracleDevice:
             st[px, 5] += n_samples
             self.traced += n_samples
 
-    def adaptive_filter(self, d_in, n, n_done, d_state, d_out, d_n_out, stream=0):
+    def filter_list(self, pl, n_done, d_state, d_out, d_n_out, stream=0):
         p = self.p
-        pin = self._view(d_in, n, np.int32)
+        pin = self._entries(pl)
         st = self._view(d_state, p.w * p.h * 6, np.float64).reshape(-1, 6)
-        out = self._view(d_out, max(n, 1), np.int32)
+        out = self._view(d_out, max(pin.size, 1), np.int32)
         k = 0
         i = n_done
         for px in pin:
@@ -70,6 +78,22 @@ class OracleDevice:
                 out[k] = px
                 k += 1
         self._view(d_n_out, 1, np.int64)[0] = k
+
+    def pack_rows(self, pl, d_state, d_rows, stream=0):
+        p = self.p
+        pix = self._entries(pl)
+        st = self._view(d_state, p.w * p.h * 6, np.float64).reshape(-1, 6)
+        if pix.size:
+            self._view(d_rows, pix.size * 6, np.float64).reshape(-1, 6)[:] = st[pix]
+
+    def unpack_rows(self, pl, world, skip_rank, d_rows, rows_per_rank, d_state, stream=0):
+        p = self.p
+        pix = self._entries(pl)
+        st = self._view(d_state, p.w * p.h * 6, np.float64).reshape(-1, 6)
+        rows = self._view(d_rows, world * rows_per_rank * 6, np.float64).reshape(world, rows_per_rank, 6)
+        for i, px in enumerate(pix):
+            if i % world != skip_rank:
+                st[px] = rows[i % world, i // world]
 
     def frame_resolve(self, d_state, d_hdr, d_count, stream=0):
         p = self.p
@@ -109,8 +133,13 @@ def _worker_body(rank, world, port, q):
     dev = OracleDevice(sc, cam)
     p = cabi.make_params(W, H, **KW)
     rounds = []
-    hdr, cnt = distributed.render_frame(dev, p, rank=rank, world=world, device=torch.device("cpu"), record_rounds=rounds)
-    q.put((rank, hdr.numpy().copy(), cnt.numpy().copy(), rounds, dev.traced))
+    hdr, cnt = distributed.render_frame(dev, p, rank=rank, world=world, device=torch.device("cpu"), record_rounds=rounds,
+                                        lag=0)
+    traced = dev.traced
+    # the pipelined schedule (bounds one round old) must give the same frame
+    hdr_l, cnt_l = distributed.render_frame(dev, p, rank=rank, world=world, device=torch.device("cpu"), lag=1)
+    assert torch.equal(hdr_l, hdr) and torch.equal(cnt_l, cnt), "lag=1 frame differs from lag=0"
+    q.put((rank, hdr.numpy().copy(), cnt.numpy().copy(), rounds, traced))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -129,8 +158,13 @@ def test_two_ranks_equal_one_rank_bit_for_bit():
     p = cabi.make_params(W, H, **KW)
     one = OracleDevice(sc, cam)
     rounds1 = []
-    hdr1, cnt1 = distributed.render_frame(one, p, device=torch.device("cpu"), record_rounds=rounds1)
+    hdr1, cnt1 = distributed.render_frame(one, p, device=torch.device("cpu"), record_rounds=rounds1, lag=0)
     hdr1, cnt1 = hdr1.numpy(), cnt1.numpy()
+    rounds_l = []
+    hdr_l, cnt_l = distributed.render_frame(one, p, device=torch.device("cpu"), record_rounds=rounds_l, lag=1)
+    assert np.array_equal(hdr_l.numpy(), hdr1) and np.array_equal(cnt_l.numpy(), cnt1)
+    # with lag 1 the host's bound of round r is the exact count of round r - 1
+    assert [b for _, b, _ in rounds_l[2:]] == [b for _, b, _ in rounds1[1:len(rounds_l) - 1]]
     # the round loop reproduces raytrace_pixel's adaptive loop exactly
     rh, rc, st = O.render(sc, cam, p, threads=2)
     assert np.array_equal(cnt1, rc) and np.array_equal(hdr1, rh)

@@ -1,0 +1,108 @@
+"""GPU tests of the round-level C ABI that multi-GPU drivers use: lists whose
+length lives on the device, sharded tracing, and the pack / unpack exchange.
+
+Several ranks are emulated on ONE GPU: every virtual rank has its own copy of the
+per-pixel state, traces its shard of each round's list, and the ranks' packed
+blocks are concatenated exactly as an all-gather would lay them out."""
+import numpy as np
+import pytest
+import torch
+
+import pathtracer_amd as pt
+from pathtracer_amd import cabi, distributed
+from conftest import scene_path
+
+pytestmark = pytest.mark.gpu
+
+W, H = 96, 72
+KW = dict(ns_aa=96, max_ray_depth=4, ns_area_light=2, samples_per_batch=16, max_tolerance=0.15, seed=5)
+
+
+def _setup(device):
+    sc = pt.Scene(scene_path("CBspheres_lambertian"))
+    device.upload(sc)
+    device.set_camera(sc.camera(W, H))
+    return cabi.make_params(W, H, **KW)
+
+
+def test_render_frame_pipelined_equals_synchronous_equals_render(device):
+    p = _setup(device)
+    cuda = torch.device("cuda", 0)
+    hdr_r, cnt_r = device.render(p)
+    assert W * H * 16 < cnt_r.sum() < W * H * 96, "the adaptive test must stop some pixels early"
+    for lag in (0, 1, 2):
+        rounds = []
+        hdr, cnt = distributed.render_frame(device, p, device=cuda, lag=lag, record_rounds=rounds)
+        assert np.array_equal(hdr.cpu().numpy(), hdr_r) and np.array_equal(cnt.cpu().numpy(), cnt_r), "lag=%d" % lag
+        bounds = [b for _, b, _ in rounds]
+        assert bounds == sorted(bounds, reverse=True)
+    st = device.stats()
+    assert st.samples == int(cnt_r.sum())
+
+
+def _virtual_ranks_frame(dev, p, world, lag):
+    """render_frame's loop with `world` ranks played in turn on one GPU."""
+    cuda = torch.device("cuda", 0)
+    npix = p.w * p.h
+    states = [torch.zeros(npix * 6, dtype=torch.float64, device=cuda) for _ in range(world)]
+    bufs = [torch.arange(npix, dtype=torch.int32, device=cuda), torch.empty(npix, dtype=torch.int32, device=cuda)]
+    n_dev = torch.full((2,), npix, dtype=torch.int64, device=cuda)
+    m0 = distributed.PixelSchedule.padded(npix, world)
+    recv = torch.full((world * m0, 6), float("nan"), dtype=torch.float64, device=cuda)
+    dev.frame_begin(p)
+    cur, done, bound, history = 0, 0, npix, []
+    while done < p.ns_aa and bound > 0:
+        if done > 0:
+            whole = cabi.PixelList(bufs[cur].data_ptr(), n_dev[cur:].data_ptr(), 0, bound, 0, 1)
+            # every rank holds the same state, so one filter stands for all of them
+            dev.filter_list(whole, done, states[0].data_ptr(), bufs[cur ^ 1].data_ptr(), n_dev[cur ^ 1:].data_ptr())
+            cur ^= 1
+            history.append(int(n_dev[cur].item()))
+            if len(history) > lag:
+                bound = min(bound, history[len(history) - 1 - lag])
+            if bound == 0:
+                break
+        ns = min(p.samples_per_batch, p.ns_aa - done)
+        whole = cabi.PixelList(bufs[cur].data_ptr(), n_dev[cur:].data_ptr(), 0, bound, 0, 1)
+        m = distributed.PixelSchedule.padded(bound, world)
+        blocks = recv[:world * m]
+        for r in range(world):
+            mine = cabi.PixelList(bufs[cur].data_ptr(), n_dev[cur:].data_ptr(), 0, bound, r, world)
+            dev.trace_list(mine, done, ns, states[r].data_ptr())
+            dev.pack_rows(mine, states[r].data_ptr(), blocks[r * m:].data_ptr())
+        for r in range(world):
+            dev.unpack_rows(whole, world, r, blocks.data_ptr(), m, states[r].data_ptr())
+        done += ns
+    torch.cuda.synchronize()
+    for r in range(1, world):
+        assert torch.equal(states[r], states[0]), "rank %d holds a different frame state" % r
+    hdr = torch.empty(npix * 3, dtype=torch.float64, device=cuda)
+    cnt = torch.empty(npix, dtype=torch.int32, device=cuda)
+    dev.frame_resolve(states[0].data_ptr(), hdr.data_ptr(), cnt.data_ptr())
+    return hdr.view(p.h, p.w, 3).cpu().numpy(), cnt.view(p.h, p.w).cpu().numpy()
+
+
+@pytest.mark.parametrize("world,lag", [(2, 0), (3, 1), (8, 1)])
+def test_virtual_ranks_reproduce_the_single_gpu_frame(device, world, lag):
+    """Sharding by (offset, stride) + pack / all-gather layout / unpack: bit-identical
+    to one GPU for any number of ranks (RNG keys are per pixel and sample)."""
+    p = _setup(device)
+    hdr_r, cnt_r = device.render(p)
+    hdr, cnt = _virtual_ranks_frame(device, p, world, lag)
+    assert np.array_equal(cnt, cnt_r) and np.array_equal(hdr, hdr_r)
+
+
+def test_list_argument_errors(device):
+    p = _setup(device)
+    device.frame_begin(p)
+    cuda = torch.device("cuda", 0)
+    buf = torch.zeros(16, dtype=torch.int32, device=cuda)
+    state = torch.zeros(W * H * 6, dtype=torch.float64, device=cuda)
+    with pytest.raises(pt.PtamdError):  # stride 0
+        device.trace_list(cabi.PixelList(buf.data_ptr(), 0, 16, 16, 0, 0), 0, 4, state.data_ptr())
+    with pytest.raises(pt.PtamdError):  # host length above its own bound
+        device.trace_list(cabi.PixelList(buf.data_ptr(), 0, 17, 16, 0, 1), 0, 4, state.data_ptr())
+    with pytest.raises(pt.PtamdError):  # unpack needs the whole list
+        device.unpack_rows(cabi.PixelList(buf.data_ptr(), 0, 16, 16, 1, 2), 2, 0, state.data_ptr(), 8, state.data_ptr())
+    # an empty shard is not an error
+    device.trace_list(cabi.PixelList(buf.data_ptr(), 0, 1, 1, 3, 4), 0, 4, state.data_ptr())

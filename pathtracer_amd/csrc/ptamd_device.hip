@@ -46,15 +46,15 @@ namespace {
 // ~90 % busy in rocprofv3), so a node visit costs 4 loads instead of the 8 of a
 // plain FP32 node or the 16 of two FP64 boxes.
 //
-// Plane k of a child is org[k] + q * 2^(e_k), exact in float by construction
-// (org is a multiple of 2^e_k and |org| / 2^e_k < 2^22), and the host rounds q
-// outward, so the decoded box CONTAINS the reference's FP64 box. Together with
-// the conservative float slab test below, a child is never culled when the
+// Plane q of axis k is org[k] + q * 2^(e_k), a float by construction (org is a
+// multiple of 2^e_k and |org| / 2^e_k < 2^22), and the host rounds q outward, so
+// the decoded box CONTAINS the reference's FP64 box. Together with the
+// conservative float slab test below, a child is never culled when the
 // reference's FP64 test (src/scene/bbox.cpp:10-47) would have accepted it; which
 // hit wins is decided by FP64 primitive tests only.
 struct alignas(64) DevNode {
   float org[3];
-  uint32_t exps;    // byte k: biased IEEE exponent of axis k's grid step
+  uint32_t exps;    // byte k: e_k as a signed 8-bit integer
   uint8_t q[4][6];  // per child: lo.xyz, hi.xyz
   int32_t child[4];
   int32_t pad[2];
@@ -136,12 +136,34 @@ struct PathBuf {
 };
 
 // ------------------------------------------------------------------ intersection
-// Ray in the form the FP32 box test wants it. The origin is kept as a float
-// interval [o_dn, o_up] containing the FP64 origin; using o_up against a box's
-// low planes and o_dn against its high planes makes every plane distance err
-// towards "box is bigger" for either sign of the direction.
+// The FP32 box test. For a node with grid origin org and step s = 2^e, the
+// distance along the ray to plane q of one axis is
+//     t*(q) = (org + q s - o) / d
+// (o, d: the ray's FP64 origin and direction). The kernel evaluates it as one FMA,
+//     t(q) = fma(q, A, B),   A = s * inv,   B = (org - of) * inv,
+// with of = float(o) and inv = v_rcp_f32(float(d)). Error budget: inv is off by
+// < 2^-22 relative (conversion 2^-24, reciprocal 1 ulp); A is exact (a power-of-two
+// scaling); B carries two more roundings; the FMA one; of differs from o by at
+// most 2^-24 |of|. Hence
+//     |t(q) - t*(q)| < (255 |A| + |B|) 2^-21 + |of inv| 2^-23.9 .
+// The test uses E = (255 |A| + |B|) 2^-20 + |of inv| 2^-22 and moves every plane
+// distance by E in the direction that makes the box bigger for this ray: the
+// plane met first (lo when A >= 0) by -E, the other by +E; both are folded into B
+// once per node, so a child costs six FMAs. The reference's four rejection tests
+// (src/scene/bbox.cpp:38) follow, with min_t rounded down and the current max_t
+// rounded up. The margin is 2^30 times the FP64 rounding of the reference's own
+// evaluation, so a child is rejected here only if the reference rejects it.
+//
+// A direction component of exactly +-0 gives inv = +-inf. Then either every
+// plane distance of that axis is NaN, which fminf/fmaxf drop (the axis does not
+// constrain, as when the reference's origin is inside the slab), or the near
+// distance is +inf / the far one -inf, which happens only for an origin outside
+// the node's slab, where the reference rejects as well.
+// Assumes scene coordinates and distances far from the ends of the float range
+// (|x| in [2^-60, 2^60]).
 struct RayF {
-  float odn[3], oup[3], inv[3];
+  float of[3], inv[3], slack[3];
+  float m0;  // max(min_t rounded down, 0)
 };
 __device__ __forceinline__ float f_down(double x) {
   float f = (float)x;
@@ -151,41 +173,24 @@ __device__ __forceinline__ float f_up(double x) {
   float f = (float)x;
   return ((double)f < x) ? nextafterf(f, INFINITY) : f;
 }
-// The reciprocal direction (Ray::inv_d, src/pathtracer/ray.h:41) is only used by
-// the box test, so it is formed in float: conversion + v_rcp_f32 (1 ulp).
-__device__ __forceinline__ RayF make_rayf(v3 o, v3 d) {
+__device__ __forceinline__ RayF make_rayf(v3 o, v3 d, double min_t) {
   RayF r;
-  r.odn[0] = f_down(o.x); r.odn[1] = f_down(o.y); r.odn[2] = f_down(o.z);
-  r.oup[0] = f_up(o.x); r.oup[1] = f_up(o.y); r.oup[2] = f_up(o.z);
+  r.of[0] = (float)o.x; r.of[1] = (float)o.y; r.of[2] = (float)o.z;
   r.inv[0] = __builtin_amdgcn_rcpf((float)d.x);
   r.inv[1] = __builtin_amdgcn_rcpf((float)d.y);
   r.inv[2] = __builtin_amdgcn_rcpf((float)d.z);
+  const float k = 2.38418579e-07f;  // 2^-22
+#pragma unroll
+  for (int a = 0; a < 3; a++) r.slack[a] = fabsf(r.of[a] * r.inv[a]) * k;
+  r.m0 = fmaxf(f_down(min_t), 0.f);
   return r;
-}
-// Conservative FP32 version of BBox::intersect (src/scene/bbox.cpp:10-47).
-// Each plane distance carries at most 4 float roundings (difference, direction
-// conversion, reciprocal, product): relative error < 2^-21.5. The entry distance
-// is therefore lowered and the exit distance raised by 2^-20 relative before the
-// reference's four rejection tests are applied. fminf/fmaxf drop NaNs (a
-// direction component of exactly 0), and the tests are written so that a NaN
-// accepts.
-__device__ __forceinline__ bool slab_f(const float lo[3], const float hi[3], const RayF &r, float min_t_dn,
-                                       float max_t_up, float &tnear) {
-  const float x0 = (lo[0] - r.oup[0]) * r.inv[0], x1 = (hi[0] - r.odn[0]) * r.inv[0];
-  const float y0 = (lo[1] - r.oup[1]) * r.inv[1], y1 = (hi[1] - r.odn[1]) * r.inv[1];
-  const float z0 = (lo[2] - r.oup[2]) * r.inv[2], z1 = (hi[2] - r.odn[2]) * r.inv[2];
-  float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
-  float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
-  const float k = 9.53674316e-07f;  // 2^-20
-  tn = tn - fabsf(tn) * k;
-  tf = tf + fabsf(tf) * k;
-  tnear = tn;
-  return !(tn > tf || tn > max_t_up || tf < min_t_dn || tf < 0.f);
 }
 
 // Per-lane traversal stack: the first STACK_LDS levels live in LDS (entry
-// (level, lane) at lds[level * blockDim.x + tid], conflict-free for any mix of
-// levels), deeper levels spill to a per-thread strip of global memory.
+// (level, lane) at lds[level * 256 + tid], conflict-free for any mix of levels),
+// deeper levels spill to a per-thread strip of global memory. LDS level
+// STACK_LDS is a scratch slot: a push that turns out not to be needed is
+// redirected there instead of being branched around.
 #ifndef PTAMD_STACK_LDS
 #define PTAMD_STACK_LDS 10
 #endif
@@ -205,18 +210,22 @@ constexpr int STACK_LDS = PTAMD_STACK_LDS;
 #else
 #define TRAV_BOUNDS __launch_bounds__(256)
 #endif
+constexpr int TRAV_BLOCK = 256;
 struct TravStack {
   uint2 *lds;
   uint2 *glob;
   uint32_t gstride, gtid;
   __device__ __forceinline__ void put(int level, uint2 e) const {
-    if (level < STACK_LDS) lds[level * blockDim.x + threadIdx.x] = e;
+    if (level < STACK_LDS) lds[level * TRAV_BLOCK + threadIdx.x] = e;
     else glob[(size_t)(level - STACK_LDS) * gstride + gtid] = e;
   }
   __device__ __forceinline__ uint2 get(int level) const {
-    if (level < STACK_LDS) return lds[level * blockDim.x + threadIdx.x];
+    if (level < STACK_LDS) return lds[level * TRAV_BLOCK + threadIdx.x];
     return glob[(size_t)(level - STACK_LDS) * gstride + gtid];
   }
+  // LDS-only forms; level STACK_LDS is the scratch slot
+  __device__ __forceinline__ void put_lds(int level, uint2 e) const { lds[level * TRAV_BLOCK + threadIdx.x] = e; }
+  __device__ __forceinline__ uint2 get_lds(int level) const { return lds[level * TRAV_BLOCK + threadIdx.x]; }
 };
 
 struct Hit {
@@ -244,16 +253,15 @@ struct Walk {
   v3 o, d;
   RayF rf;
   double min_t, max_t0, best_t;
-  float min_f, best_f;
+  float best_f;
   Hit hit;
   int sp;
   int32_t cur;
 
   __device__ __forceinline__ void begin(const DevScene &S, v3 o_, v3 d_, double tmin, double tmax) {
     o = o_; d = d_;
-    rf = make_rayf(o, d);
+    rf = make_rayf(o, d, tmin);
     min_t = tmin; max_t0 = tmax;
-    min_f = f_down(tmin);
     best_t = tmax;
     best_f = f_up(tmax);
     hit.prim = -1; hit.t = tmax; hit.u = 0; hit.v = 0;
@@ -264,12 +272,22 @@ struct Walk {
   // pop, skipping subtrees that begin beyond the current hit
   __device__ __forceinline__ void pop(const TravStack &stack) {
     cur = CHILD_EMPTY;
-    while (sp > 0) {
-      sp--;
-      const uint2 e = stack.get(sp);
-      if (__uint_as_float(e.y) > best_f) continue;
-      cur = (int32_t)e.x;
-      break;
+    if (sp <= STACK_LDS) {
+      while (sp > 0) {
+        sp--;
+        const uint2 e = stack.get_lds(sp);
+        if (__uint_as_float(e.y) > best_f) continue;
+        cur = (int32_t)e.x;
+        break;
+      }
+    } else {
+      while (sp > 0) {
+        sp--;
+        const uint2 e = stack.get(sp);
+        if (__uint_as_float(e.y) > best_f) continue;
+        cur = (int32_t)e.x;
+        break;
+      }
     }
   }
 
@@ -281,26 +299,38 @@ struct Walk {
     const uint4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3];
     if (COUNT) n_nodes += 4;
     const float org[3] = {__uint_as_float(w0.x), __uint_as_float(w0.y), __uint_as_float(w0.z)};
-    const float sc[3] = {__uint_as_float((w0.w & 0xffu) << 23), __uint_as_float(((w0.w >> 8) & 0xffu) << 23),
-                         __uint_as_float(((w0.w >> 16) & 0xffu) << 23)};
+    float A[3], Blo[3], Bhi[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      const int e = (int)(w0.w << (24 - 8 * a)) >> 24;  // signed byte a
+      A[a] = __builtin_ldexpf(rf.inv[a], e);
+      const float B = (org[a] - rf.of[a]) * rf.inv[a];
+      const float E = fmaf(fmaf(fabsf(A[a]), 255.f, fabsf(B)), 9.53674316e-07f /* 2^-20 */, rf.slack[a]);
+      const float cE = copysignf(E, A[a]);
+      Blo[a] = B - cE;
+      Bhi[a] = B + cE;
+    }
     // 24 quantised bytes: w1.xyzw, w2.xy; codes: w2.zw, w3.xy
     const uint32_t qw[6] = {w1.x, w1.y, w1.z, w1.w, w2.x, w2.y};
     int32_t c[4] = {(int32_t)w2.z, (int32_t)w2.w, (int32_t)w3.x, (int32_t)w3.y};
     float t[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-      float lo[3], hi[3];
+      float tn = -FINF, tf = FINF;
 #pragma unroll
       for (int a = 0; a < 3; a++) {
         const int bl = k * 6 + a, bh = k * 6 + 3 + a;
         const float ql = (float)((qw[bl >> 2] >> ((bl & 3) * 8)) & 0xffu);
         const float qh = (float)((qw[bh >> 2] >> ((bh & 3) * 8)) & 0xffu);
-        lo[a] = fmaf(ql, sc[a], org[a]);  // exact: see DevNode
-        hi[a] = fmaf(qh, sc[a], org[a]);
+        const float tl = fmaf(ql, A[a], Blo[a]);
+        const float th = fmaf(qh, A[a], Bhi[a]);
+        tn = fmaxf(tn, fminf(tl, th));
+        tf = fminf(tf, fmaxf(tl, th));
       }
-      if (!(c[k] != CHILD_EMPTY && slab_f(lo, hi, rf, min_f, best_f, t[k]))) t[k] = FINF;
-      // an accepted child whose entry distance came out NaN still has to be visited
-      if (t[k] != t[k]) t[k] = -FINF;
+      // bbox.cpp:38 with NaNs (dropped above) accepting: reject iff
+      // max(tn, min_t, 0) > min(tf, max_t)
+      const float lo2 = fmaxf(tn, rf.m0), hi2 = fminf(tf, best_f);
+      t[k] = (c[k] != CHILD_EMPTY && !(lo2 > hi2)) ? lo2 : FINF;
     }
     cswap(t[0], c[0], t[1], c[1]);
     cswap(t[2], c[2], t[3], c[3]);
@@ -308,9 +338,19 @@ struct Walk {
     cswap(t[1], c[1], t[3], c[3]);
     cswap(t[1], c[1], t[2], c[2]);
     if (t[0] < FINF) {
-      if (t[3] < FINF) { stack.put(sp, make_uint2((uint32_t)c[3], __float_as_uint(t[3]))); sp++; }
-      if (t[2] < FINF) { stack.put(sp, make_uint2((uint32_t)c[2], __float_as_uint(t[2]))); sp++; }
-      if (t[1] < FINF) { stack.put(sp, make_uint2((uint32_t)c[1], __float_as_uint(t[1]))); sp++; }
+      // the accepted children are a prefix of the sorted four; the farthest goes
+      // deepest. nv = accepted among 1..3; c[k] lands on level sp + nv - k.
+      const int nv = (t[1] < FINF) + (t[2] < FINF) + (t[3] < FINF);
+      if (sp + 3 <= STACK_LDS) {
+#pragma unroll
+        for (int k = 1; k < 4; k++)
+          stack.put_lds(k <= nv ? sp + nv - k : STACK_LDS, make_uint2((uint32_t)c[k], __float_as_uint(t[k])));
+      } else {
+#pragma unroll
+        for (int k = 1; k < 4; k++)
+          if (k <= nv) stack.put(sp + nv - k, make_uint2((uint32_t)c[k], __float_as_uint(t[k])));
+      }
+      sp += nv;
       cur = c[0];
     } else {
       pop(stack);
@@ -1371,7 +1411,7 @@ static bool quantize_node(DevNode &n, const double boxes[][6], int nk) {
       }
       if (!ok || (double)(float)org != org) continue;
       n.org[a] = (float)org;
-      n.exps |= (uint32_t)(e + 127) << (8 * a);
+      n.exps |= (uint32_t)(uint8_t)(int8_t)e << (8 * a);
       for (int k = 0; k < nk; k++) { n.q[k][a] = q[k][0]; n.q[k][3 + a] = q[k][1]; }
       break;
     }
@@ -1619,8 +1659,8 @@ struct TravLaunch {
   uint2 *gstack;
 };
 static int traversal_launch(ptamd_context *c, TravLaunch *t) {
-  t->block = 256;
-  t->lds = (size_t)t->block * std::min(c->S.stack_cap, (int32_t)STACK_LDS) * sizeof(uint2);
+  t->block = TRAV_BLOCK;
+  t->lds = (size_t)t->block * (STACK_LDS + 1) * sizeof(uint2);  // + the scratch level
   // resident workgroups per CU: bounded by LDS (160 KiB per CU) and by registers
   // (about 5 waves per SIMD). The waves are persistent, so the grid is exactly
   // the resident set

@@ -203,7 +203,10 @@ constexpr int STACK_LDS = PTAMD_STACK_LDS;
 #define PTAMD_WAVES_PER_EU 6
 #endif
 #ifndef PTAMD_GRID_MULT
-#define PTAMD_GRID_MULT 4
+#define PTAMD_GRID_MULT 8
+#endif
+#ifndef PTAMD_NODE_STEPS
+#define PTAMD_NODE_STEPS 2
 #endif
 #if PTAMD_WAVES_PER_EU > 0
 #define TRAV_BOUNDS __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PTAMD_WAVES_PER_EU, PTAMD_WAVES_PER_EU)))
@@ -427,9 +430,15 @@ __device__ __forceinline__ void trace_rays(const DevScene &S, const Policy &pol,
     double tmin, tmax;
     pol.load(i, o, d, tmin, tmax);
     w.begin(S, o, d, tmin, tmax);
+    // One trip: PTAMD_NODE_STEPS box steps for the lanes at a node, then a
+    // primitive test for the lanes at a primitive (which includes lanes a box step
+    // just brought there). Running the two kinds of step one after the other,
+    // instead of one kind per trip, keeps more lanes busy per instruction.
     while (w.cur != CHILD_EMPTY) {
-      if (w.cur >= 0) w.template node_step<COUNT>(S, stack, n_nodes);
-      else if (w.template prim_step<ANY, COUNT>(S, stack, n_tests)) break;
+#pragma unroll
+      for (int k = 0; k < PTAMD_NODE_STEPS; k++)
+        if (w.cur >= 0) w.template node_step<COUNT>(S, stack, n_nodes);
+      if (w.cur < 0 && w.cur != CHILD_EMPTY && w.template prim_step<ANY, COUNT>(S, stack, n_tests)) break;
     }
     pol.store(i, w.hit, w.hit.prim >= 0);
   }

@@ -119,16 +119,27 @@ struct HitBuf {
   int32_t *prim;
   double *t, *u, *v;
 };
+// Per light sample (slot = entry * nls + q) the records are arrays of 32-byte
+// structures: the nls samples of one vertex are written by one lane of k_shade as
+// one contiguous run, and a shadow ray or a resolve reads its record with two
+// 16-byte loads.
+struct alignas(32) SRay {
+  double d[3];
+  double max_t;  // hemisphere mode: cos term instead
+};
+struct alignas(32) Contrib {
+  double c[3];
+  double pad;
+};
 struct ShadowQ {
-  int32_t *slot;     // entry * nls + q
-  double *d[3];
-  double *max_t;     // hemisphere mode: cos term instead
+  int32_t *slot;  // entry * nls + q
+  SRay *ray;      // [cap * nls]
 };
 struct VertexBuf {
-  double *hp[3];      // hit point per queue entry (shadow-ray origin)
-  uint8_t *flag;      // bit 0: has light samples, bit 1: result goes to `pending`
-  double *contrib[3]; // [cap * nls]
-  uint8_t *vis;       // [cap * nls]
+  double *hp[3];     // hit point per queue entry (shadow-ray origin)
+  uint8_t *flag;     // bit 0: has light samples, bit 1: result goes to `pending`
+  Contrib *contrib;  // [cap * nls]
+  uint8_t *vis;      // [cap * nls]
 };
 struct PathBuf {
   double *rad[3];
@@ -651,9 +662,10 @@ struct ShadowPolicy {
     const int32_t slot = sq.slot[i];
     const uint32_t e = (uint32_t)slot / nls;
     o = V(vb.hp[0][e], vb.hp[1][e], vb.hp[2][e]);
-    d = V(sq.d[0][slot], sq.d[1][slot], sq.d[2][slot]);
+    const SRay r = sq.ray[slot];
+    d = V(r.d[0], r.d[1], r.d[2]);
     tmin = PT_EPS_D;
-    tmax = HEMI ? (double)INFINITY : sq.max_t[slot];
+    tmax = HEMI ? (double)INFINITY : r.max_t;
   }
   __device__ __forceinline__ void store(uint32_t i, const Hit &h, bool found) const {
     const int32_t slot = sq.slot[i];
@@ -665,9 +677,10 @@ struct ShadowPolicy {
         v3 light_L = V(0, 0, 0);
         if (S.mat_kind[m] == PTAMD_MAT_EMISSION) light_L = V(S.mat_param[3 * m], S.mat_param[3 * m + 1], S.mat_param[3 * m + 2]);
         // f * light_L * dot(wi, w2o*n) * 2 * PI; f waits in the contrib slot, the cosine in max_t
-        const v3 f = V(vb.contrib[0][slot], vb.contrib[1][slot], vb.contrib[2][slot]);
-        const v3 term = vscale(vscale(vscale(vmul(f, light_L), sq.max_t[slot]), 2), PT_PI);
-        vb.contrib[0][slot] = term.x; vb.contrib[1][slot] = term.y; vb.contrib[2][slot] = term.z;
+        const Contrib cf = vb.contrib[slot];
+        const v3 f = V(cf.c[0], cf.c[1], cf.c[2]);
+        const v3 term = vscale(vscale(vscale(vmul(f, light_L), sq.ray[slot].max_t), 2), PT_PI);
+        vb.contrib[slot] = Contrib{{term.x, term.y, term.z}, 0.0};
       }
       vb.vis[slot] = found ? 1 : 0;
     }
@@ -688,6 +701,22 @@ __global__ void TRAV_BOUNDS
     atomicAdd(&ctl->st_tests, (unsigned long long)ct);
   }
 }
+
+// Visibility bytes of consecutive slots, stored four at a time when a vertex's run
+// of slots is word-aligned (nls a multiple of 4).
+struct VisWriter {
+  uint8_t *vis;
+  bool words;
+  uint32_t acc;
+  __device__ __forceinline__ void put(size_t slot, uint32_t v) {
+    if (!words) { vis[slot] = (uint8_t)v; return; }
+    acc |= v << (8 * (slot & 3));
+    if ((slot & 3) == 3) {
+      *reinterpret_cast<uint32_t *>(vis + (slot & ~(size_t)3)) = acc;
+      acc = 0;
+    }
+  }
+};
 
 struct Compact {
   uint8_t *pflag;        // [cap] entry pushes a bounce ray
@@ -804,6 +833,7 @@ __global__ void __launch_bounds__(256)
       cp.pflag[i] = push ? 1 : 0;
     }
     // ---- light samples into their slots (estimate_direct_lighting_*, pathtracer.cpp:47-135)
+    VisWriter vis{vb.vis, (nls & 3) == 0, 0u};
     if (do_nee) {
       int qq = 0;
       if (!fp.hemisphere) {
@@ -820,13 +850,12 @@ __global__ void __launch_bounds__(256)
             const size_t slot = (size_t)i * nls + qq;
             if (!(wi_o.z < 0 || (radiance.x == 0 && radiance.y == 0 && radiance.z == 0))) {
               const v3 term = vdivs(vscale(vmul(f, radiance), fabs(wi_o.z)), pdf);
-              sq.d[0][slot] = wi.x; sq.d[1][slot] = wi.y; sq.d[2][slot] = wi.z;
-              sq.max_t[slot] = dist;
-              vb.contrib[0][slot] = term.x; vb.contrib[1][slot] = term.y; vb.contrib[2][slot] = term.z;
-              vb.vis[slot] = 2;
+              sq.ray[slot] = SRay{{wi.x, wi.y, wi.z}, dist};
+              vb.contrib[slot] = Contrib{{term.x, term.y, term.z}, 0.0};
+              vis.put(slot, 2);
               n_emit++;
             } else {
-              vb.vis[slot] = 0;
+              vis.put(slot, 0);
             }
           }
         }
@@ -838,15 +867,14 @@ __global__ void __launch_bounds__(256)
           const v3 wd3 = mmul(o2w, wi);
           const double cs = vdot(wi, mmul(w2o, n_sh));
           const size_t slot = (size_t)i * nls + qq;
-          sq.d[0][slot] = wd3.x; sq.d[1][slot] = wd3.y; sq.d[2][slot] = wd3.z;
-          sq.max_t[slot] = cs;
-          vb.contrib[0][slot] = f.x; vb.contrib[1][slot] = f.y; vb.contrib[2][slot] = f.z;
-          vb.vis[slot] = 2;
+          sq.ray[slot] = SRay{{wd3.x, wd3.y, wd3.z}, cs};
+          vb.contrib[slot] = Contrib{{f.x, f.y, f.z}, 0.0};
+          vis.put(slot, 2);
           n_emit++;
         }
       }
     } else if (valid && nls > 0) {
-      for (int qq = 0; qq < nls; qq++) vb.vis[(size_t)i * nls + qq] = 0;
+      for (int qq = 0; qq < nls; qq++) vis.put((size_t)i * nls + qq, 0);
     }
     // ---- bounce ray at this entry's position in the next ray arrays
     if (push) {
@@ -961,8 +989,24 @@ __global__ void k_resolve(FrameParams fp, RayQ q, const int32_t *__restrict__ li
         verts++;
         v3 L = V(0, 0, 0);
         const size_t b = (size_t)i * nls;
-        for (int qq = 0; qq < nls; qq++) {
-          if (vb.vis[b + qq] == 1) L = vadd(L, V(vb.contrib[0][b + qq], vb.contrib[1][b + qq], vb.contrib[2][b + qq]));
+        if ((nls & 3) == 0) {
+          for (int q4 = 0; q4 < nls; q4 += 4) {
+            const uint32_t vw = *reinterpret_cast<const uint32_t *>(vb.vis + b + q4);
+#pragma unroll
+            for (int qq = 0; qq < 4; qq++) {
+              if (((vw >> (8 * qq)) & 0xffu) == 1u) {
+                const Contrib cc = vb.contrib[b + q4 + qq];
+                L = vadd(L, V(cc.c[0], cc.c[1], cc.c[2]));
+              }
+            }
+          }
+        } else {
+          for (int qq = 0; qq < nls; qq++) {
+            if (vb.vis[b + qq] == 1) {
+              const Contrib cc = vb.contrib[b + qq];
+              L = vadd(L, V(cc.c[0], cc.c[1], cc.c[2]));
+            }
+          }
         }
         L = vscale(L, 1. / (double)nls);
         const uint32_t j = list ? (uint32_t)list[i] : i;
@@ -1251,11 +1295,11 @@ int ensure_buffers(ptamd_context *c, int64_t paths, int nls, bool pend) {
   off_hit[0] = take(P * 4);
   for (int j = 1; j < 4; j++) off_hit[j] = take(P * 8);
   off_sq[0] = take(PN * 4);
-  for (int j = 1; j < 5; j++) off_sq[j] = take(PN * 8);
+  off_sq[1] = take(PN * sizeof(SRay));
   for (int j = 0; j < 3; j++) off_vb[j] = take(P * 8);
   off_vb[3] = take(P);
-  for (int j = 4; j < 7; j++) off_vb[j] = take(PN * 8);
-  off_vb[7] = take(PN);
+  off_vb[4] = take(PN * sizeof(Contrib));
+  off_vb[7] = take(PN + 4);
   for (int j = 0; j < 6; j++) off_pb[j] = take(P * 8);
   for (int k = 0; k < 2; k++) off_list[k] = take(P * 4);
   off_cp[0] = take(P);
@@ -1277,11 +1321,10 @@ int ensure_buffers(ptamd_context *c, int64_t paths, int nls, bool pend) {
   c->hb.u = (double *)(b + off_hit[2]);
   c->hb.v = (double *)(b + off_hit[3]);
   c->sq.slot = (int32_t *)(b + off_sq[0]);
-  for (int j = 0; j < 3; j++) c->sq.d[j] = (double *)(b + off_sq[1 + j]);
-  c->sq.max_t = (double *)(b + off_sq[4]);
+  c->sq.ray = (SRay *)(b + off_sq[1]);
   for (int j = 0; j < 3; j++) c->vb.hp[j] = (double *)(b + off_vb[j]);
   c->vb.flag = (uint8_t *)(b + off_vb[3]);
-  for (int j = 0; j < 3; j++) c->vb.contrib[j] = (double *)(b + off_vb[4 + j]);
+  c->vb.contrib = (Contrib *)(b + off_vb[4]);
   c->vb.vis = (uint8_t *)(b + off_vb[7]);
   for (int j = 0; j < 3; j++) {
     c->pb.rad[j] = (double *)(b + off_pb[j]);

@@ -428,13 +428,23 @@ struct Walk {
 // Traces a list of rays, one ray per lane per grid-stride step. Policy:
 // load(i, o, d, min_t, max_t) reads ray i; store(i, hit, found) writes its result.
 //
-// (A persistent-wave driver that refilled finished lanes from a shared counter
-// and batched primitive tests was measured too: 1.3x to 1.6x slower on MI355X,
-// the refilled lanes' rays being out of step with their neighbours.)
+// Measured on MI355X and rejected:
+//  * persistent waves that hand finished lanes a new ray (refilling at once, or
+//    once 16 / 32 / 48 lanes are idle): 1.6x to 1.9x slower although a wave's
+//    slowest ray takes about three times the average number of trips. Lanes that
+//    start together share the top of the tree (one cache line serves the wave);
+//    refilled lanes are everywhere in the tree at once and every trip waits for
+//    an L2 access;
+//  * sorting each workgroup's 256 rays by direction octant: no gain;
+//  * one box step or one primitive test per trip (if / else), or box steps until
+//    every lane has a primitive (while-while): 5 % and 25 % slower.
 template <bool ANY, bool COUNT, class Policy>
 __device__ __forceinline__ void trace_rays(const DevScene &S, const Policy &pol, uint32_t n, const TravStack &stack,
                                            uint32_t &n_nodes, uint32_t &n_tests) {
   Walk w;
+  // (Cutting the list into one contiguous band per XCD, so that each XCD's L2
+  // would hold only its band's share of the scene, was measured 12 % slower: the
+  // bands differ in cost and the XCDs with easy bands idle.)
   const uint32_t stride = gridDim.x * blockDim.x;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     v3 o, d;

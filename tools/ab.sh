@@ -8,6 +8,6 @@ for v in "$@"; do
   timeout -k 10 200 python3 bench.py --scene bunny --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/ab/${v}_bunny.json 2> gpurun_out/ab/${v}_bunny.err
   timeout -k 10 300 python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/ab/${v}_dragon.json 2> gpurun_out/ab/${v}_dragon.err
   echo "== $v"
-  python3 tools/bench_brief.py gpurun_out/ab/${v}_bunny.json | head -2
-  python3 tools/bench_brief.py gpurun_out/ab/${v}_dragon.json | head -2
+  python3 tools/bench_brief.py gpurun_out/ab/${v}_bunny.json | sed -n 1,2p
+  python3 tools/bench_brief.py gpurun_out/ab/${v}_dragon.json | sed -n 1,2p
 done

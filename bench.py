@@ -47,7 +47,7 @@ def parse_args():
     ap.add_argument("--depth", type=int, default=5)
     ap.add_argument("--max-paths", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-spp", type=int, default=64)
+    ap.add_argument("--cpu-spp", type=int, default=256)
     return ap.parse_args()
 
 
@@ -106,6 +106,25 @@ def cpu_leg(scene_path, args, spp, threads_port):
             s = ptar.load(tmp)["stats"]
             out["reference"] = {"value": float(s[3] / s[0]), "cores": threads_ref}
     return out
+
+
+def profiled_traffic(scene, kernel):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this
+    workload (profiles/, separate FETCH_SIZE and WRITE_SIZE runs). FETCH_SIZE is in KiB and,
+    on gfx950, counts 128-byte read requests as 64 bytes, hence the factor 2."""
+    names = {"extend": "k_extend<false>", "shadow": "k_shadow<false, false>", "shade": "k_shade",
+             "resolve": "k_resolve"}
+    path = os.path.join(ROOT, "profiles", "r01b_%s_summary.json" % scene)
+    if kernel not in names or not os.path.exists(path):
+        return None, None
+    try:
+        d = json.load(open(path))
+        f = d["pmc_fetch"][names[kernel]]
+        w = d["pmc_write"][names[kernel]]
+        per_launch = (2.0 * f["FETCH_SIZE"] * 1024 / f["_dispatches"]) + (w["WRITE_SIZE"] * 1024 / w["_dispatches"])
+        return per_launch, os.path.relpath(path, ROOT)
+    except Exception:
+        return None, None
 
 
 def main():
@@ -230,7 +249,10 @@ def main():
                 ach = rays * b / (ms * 1e-3) / 1e9 if ms > 0 else None
                 roof.update({"achieved": ach, "frac": ach / HBM_PEAK_GBS if ach else None,
                              "bytes_per_ray": b, "rays_per_launch": rays / max(agg["launches"][dom], 1),
+                             "algorithmic_bytes_per_launch": rays * b / max(agg["launches"][dom], 1),
                              "avg_launch_ms": ms / max(agg["launches"][dom], 1)})
+                if args.scene in ("dragon", "bunny") and (args.width, args.height) == (800, 600):
+                    roof["traffic"], roof["traffic_source"] = profiled_traffic(args.scene, names[dom])
             # whole-frame figure: samples/s x algorithmic bytes per sample
             b_sample = (ext_rays * b_ext + agg["shadow"] * b_sh + 72 * agg["vertices"]) / max(total_samples, 1) + 16
             roof["bytes_per_sample"] = b_sample

@@ -17,4 +17,6 @@ run_pass pmc_write --pmc WRITE_SIZE || exit 1
 run_pass pmc_l2 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum || exit 1
 run_pass pmc_sq --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY || exit 1
 run_pass pmc_grbm --pmc GRBM_GUI_ACTIVE GRBM_COUNT || exit 1
+run_pass pmc_sq2 --pmc SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT || exit 1
+run_pass pmc_l1 --pmc TCP_GATE_EN1_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum TD_TD_BUSY_sum TD_TC_STALL_sum || exit 1
 echo passes done

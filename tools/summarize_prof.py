@@ -37,7 +37,7 @@ def counters(d, name):
 def main():
     d = sys.argv[1]
     res = {"kernels": kernel_stats(d)}
-    for p in ("pmc_fetch", "pmc_write", "pmc_l2", "pmc_sq", "pmc_grbm"):
+    for p in ("pmc_fetch", "pmc_write", "pmc_l2", "pmc_sq", "pmc_grbm", "pmc_sq2", "pmc_l1"):
         res[p] = counters(d, p)
     try:
         res["bench"] = json.load(open(os.path.join(d, "trace.json")))
@@ -49,7 +49,7 @@ def main():
         print("%-34s %6d %10.2f %9.1f %6.2f" % (k, v["calls"], v["total_ms"], v["avg_us"], v["pct"]))
     for k in ("k_extend<false>", "k_shadow<false, false>", "k_shade", "k_resolve"):
         row = {}
-        for p in ("pmc_fetch", "pmc_write", "pmc_l2", "pmc_sq", "pmc_grbm"):
+        for p in ("pmc_fetch", "pmc_write", "pmc_l2", "pmc_sq", "pmc_grbm", "pmc_sq2", "pmc_l1"):
             row.update({c: v for c, v in res[p].get(k, {}).items() if not c.startswith("_")})
         if row:
             hit = row.get("TCC_HIT_sum", 0) / max(row.get("TCC_HIT_sum", 0) + row.get("TCC_MISS_sum", 0), 1)

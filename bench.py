@@ -48,6 +48,10 @@ def parse_args():
     ap.add_argument("--max-paths", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-spp", type=int, default=256)
+    ap.add_argument("--target-paths", type=int, default=4 << 20, help="see PixelSchedule.batches")
+    ap.add_argument("--max-batches", type=int, default=32)
+    ap.add_argument("--pixel-stride", type=int, default=1,
+                    help="rehearsal: render every K-th pixel only, i.e. the work of one rank of K")
     return ap.parse_args()
 
 
@@ -166,7 +170,9 @@ def main():
     def frame(seed):
         p = cabi.make_params(args.width, args.height, ns_aa=spp, max_ray_depth=args.depth,
                              ns_area_light=args.light_samples, seed=seed)
-        hdr, cnt = distributed.render_frame(dev, p, rank=rank, world=world, device=device)
+        hdr, cnt = distributed.render_frame(dev, p, rank=rank, world=world, device=device,
+                                            pixel_stride=args.pixel_stride, target_paths=args.target_paths,
+                                            max_batches=args.max_batches)
         return cnt
 
     for i in range(args.warmup):

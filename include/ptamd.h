@@ -196,10 +196,17 @@ typedef struct ptamd_pixel_list {
   int64_t n_max;
   int32_t offset, stride;
 } ptamd_pixel_list;
-/* ptamd_trace_pixels for a shard of a list whose length lives on the device. */
+/* ptamd_trace_pixels for a shard of a list whose length lives on the device.
+ * n_samples may span several batches of samples_per_batch: the adaptive test of
+ * pathtracer.cpp:250-258 is then applied between the batches while the samples
+ * are summed, and samples traced past a pixel's stop are dropped, so the state
+ * is what one call per batch with a filter in between would have left. Tracing
+ * ahead like this is how small rounds are kept from leaving the GPU idle. */
 int ptamd_trace_list(ptamd_context *ctx, const ptamd_pixel_list *list, int32_t sample_base,
                      int32_t n_samples, double *d_state, void *stream);
-/* ptamd_adaptive_filter for such a list (offset 0, stride 1). */
+/* ptamd_adaptive_filter for such a list (offset 0, stride 1). A pixel survives if
+ * it used all n_done samples traced for it so far (it did not stop at a test
+ * inside an earlier multi-batch round) and the test at i = n_done lets it go on. */
 int ptamd_filter_list(ptamd_context *ctx, const ptamd_pixel_list *in, int32_t n_done, const double *d_state,
                       int32_t *d_pixels_out, int64_t *d_n_out, void *stream);
 /* The exchange after a round, the counterpart of the reference's shared

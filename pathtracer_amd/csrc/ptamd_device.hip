@@ -556,7 +556,6 @@ __global__ void k_set_counts(Ctl *ctl, PixView pv, uint32_t p0, uint32_t chunk, 
   ctl->n_cur = np * ns;
   ctl->n_next = 0;
   ctl->n_shadow = 0;
-  ctl->st_samples += (unsigned long long)np * ns;
 }
 
 // end of one depth: fold the stage's counts into the statistics, make the next
@@ -1039,30 +1038,14 @@ __global__ void k_resolve(FrameParams fp, RayQ q, const int32_t *__restrict__ li
 // Vector3D::illum (CGL/include/CGL/vector3D.h:231-233): double arithmetic, float result
 __device__ __forceinline__ float illum(v3 v) { return (float)(0.2126f * v.x + 0.7152f * v.y + 0.0722f * v.z); }
 
-// Folds the round's finished paths into the per-pixel sums, in sample order
-// (pathtracer.cpp:262-266). state: [pixel*6] = s1, s2, sum.rgb, n.
-__global__ void k_accumulate(PixView pv, uint32_t p0, const Ctl *ctl, int32_t ns, PathBuf pb,
-                             double *__restrict__ state) {
-  const uint32_t stride = gridDim.x * blockDim.x;
-  const uint32_t n_pixels = ctl->n_pix;
-  for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n_pixels; p += stride) {
-    double *st = state + (size_t)pv.at(p0 + p) * 6;
-    double s1 = st[0], s2 = st[1];
-    v3 sum = V(st[2], st[3], st[4]);
-    const size_t b = (size_t)p * (uint32_t)ns;
-    for (int s = 0; s < ns; s++) {
-      const v3 L = V(pb.rad[0][b + s], pb.rad[1][b + s], pb.rad[2][b + s]);
-      const double xl = illum(L);
-      s1 += xl;
-      s2 += xl * xl;
-      sum = vadd(sum, L);
-    }
-    st[0] = s1; st[1] = s2; st[2] = sum.x; st[3] = sum.y; st[4] = sum.z;
-    st[5] += (double)ns;
-  }
-}
-
 // The adaptive test of pathtracer.cpp:250-258 at i = n_done.
+// A pixel of a round's list goes on to the next round if it used every sample
+// traced for it so far (it did not stop at a test inside an earlier round) and the
+// test at i = n_done says so.
+__device__ __forceinline__ bool pixel_continues(const double *st, int32_t i, double tol);
+__device__ __forceinline__ bool pixel_survives(const double *st, int32_t n_done, double tol) {
+  return st[5] >= (double)n_done && pixel_continues(st, n_done, tol);
+}
 __device__ __forceinline__ bool pixel_continues(const double *st, int32_t i, double tol) {
   const double s1 = st[0], s2 = st[1];
   const double one_over_i = 1.0 / i, one_over_im1 = 1.0 / (i - 1);
@@ -1072,6 +1055,39 @@ __device__ __forceinline__ bool pixel_continues(const double *st, int32_t i, dou
   return !(I <= tol * mean);
 }
 
+// Folds the round's finished paths into the per-pixel sums, in sample order:
+// the loop of raytrace_pixel (pathtracer.cpp:249-267) over radiances that are
+// already computed. A round may hold several batches of a pixel, traced ahead of
+// their adaptive tests; the test runs here between the batches, and what was
+// traced past a pixel's stop is dropped. state: [pixel*6] = s1, s2, sum.rgb, n.
+__global__ void k_accumulate(PixView pv, uint32_t p0, Ctl *ctl, int32_t sample_base, int32_t ns, int32_t batch,
+                             double tol, PathBuf pb, double *__restrict__ state) {
+  const uint32_t stride = gridDim.x * blockDim.x;
+  const uint32_t n_pixels = ctl->n_pix;
+  unsigned long long kept = 0;
+  for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n_pixels; p += stride) {
+    double *st = state + (size_t)pv.at(p0 + p) * 6;
+    double acc[2] = {st[0], st[1]};
+    v3 sum = V(st[2], st[3], st[4]);
+    const size_t b = (size_t)p * (uint32_t)ns;
+    int s = 0;
+    for (; s < ns; s++) {
+      const int i = sample_base + s;
+      if (s > 0 && i % batch == 0 && !pixel_continues(acc, i, tol)) break;
+      const v3 L = V(pb.rad[0][b + s], pb.rad[1][b + s], pb.rad[2][b + s]);
+      const double xl = illum(L);
+      acc[0] += xl;
+      acc[1] += xl * xl;
+      sum = vadd(sum, L);
+    }
+    st[0] = acc[0]; st[1] = acc[1]; st[2] = sum.x; st[3] = sum.y; st[4] = sum.z;
+    st[5] += (double)s;
+    kept += (unsigned long long)s;
+  }
+  for (int off = 32; off > 0; off >>= 1) kept += __shfl_down(kept, off);
+  if ((threadIdx.x & 63) == 0 && kept) atomicAdd(&ctl->st_samples, kept);
+}
+
 // Ordered stream compaction of the still-active pixels, three small kernels:
 // per-block counts, scan of the counts, scatter.
 __global__ void k_filter_count(PixView pv, int32_t n_done, double tol, const double *__restrict__ state,
@@ -1079,7 +1095,7 @@ __global__ void k_filter_count(PixView pv, int32_t n_done, double tol, const dou
   __shared__ uint32_t wave_cnt[4];
   const uint32_t n = pv.count();
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool keep = i < n && pixel_continues(state + (size_t)pv.at(i) * 6, n_done, tol);
+  const bool keep = i < n && pixel_survives(state + (size_t)pv.at(i) * 6, n_done, tol);
   const unsigned long long m = __ballot(keep);
   if (__lane_id() == 0) wave_cnt[threadIdx.x >> 6] = (uint32_t)__popcll(m);
   __syncthreads();
@@ -1114,7 +1130,7 @@ __global__ void k_filter_scatter(PixView pv, int32_t n_done, double tol, const d
   __shared__ uint32_t wave_cnt[4];
   const uint32_t n = pv.count();
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool keep = i < n && pixel_continues(state + (size_t)pv.at(i) * 6, n_done, tol);
+  const bool keep = i < n && pixel_survives(state + (size_t)pv.at(i) * 6, n_done, tol);
   const unsigned long long m = __ballot(keep);
   const int lane = __lane_id(), wv = threadIdx.x >> 6;
   if (lane == 0) wave_cnt[wv] = (uint32_t)__popcll(m);
@@ -1835,7 +1851,8 @@ int ptamd_trace_list(ptamd_context *c, const ptamd_pixel_list *list, int32_t sam
       cur ^= 1;
     }
     L.begin(PTAMD_K_ACCUMULATE);
-    hipLaunchKernelGGL(k_accumulate, ggrid, 256, 0, s, pv, up0, c->ctl, n_samples, pb, d_state);
+    hipLaunchKernelGGL(k_accumulate, ggrid, 256, 0, s, pv, up0, c->ctl, sample_base, n_samples,
+                       c->params.samples_per_batch, c->params.max_tolerance, pb, d_state);
     L.end();
   }
   HIPCHK(hipGetLastError());
@@ -2018,7 +2035,11 @@ int ptamd_render(ptamd_context *c, const ptamd_render_params *p, double *hdr_out
       }
       l = ptamd_pixel_list{d_list[cur], d_n + cur, 0, n_known, 0, 1};
     }
-    const int ns = std::min(p->samples_per_batch, p->ns_aa - done);
+    // a round too small to fill the GPU traces several batches per pixel ahead of
+    // their adaptive tests (k_accumulate applies them and drops what was not needed)
+    const int64_t paths = n_known * p->samples_per_batch;
+    int64_t k = std::max<int64_t>(1, std::min<int64_t>((4 << 20) / std::max<int64_t>(paths, 1), 32));
+    const int ns = (int)std::min<int64_t>(k * p->samples_per_batch, p->ns_aa - done);
     rc = ptamd_trace_list(c, &l, done, ns, d_state, s);
     if (rc) { cleanup(); return rc; }
     done += ns;

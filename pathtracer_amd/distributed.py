@@ -47,8 +47,26 @@ class PixelSchedule:
     def padded(n_active, world):
         return math.ceil(n_active / world) if n_active else 0
 
+    @staticmethod
+    def batches(n_active_bound, world, batch, samples_left, target_paths, max_batches):
+        """How many batches of `batch` samples a round traces per pixel.
 
-def render_frame(dev, params, rank=0, world=1, group=None, device=None, record_rounds=None, lag=1):
+        A launch of fewer than `target_paths` paths leaves most of the GPU idle and
+        still takes as long as its slowest ray, so when a rank's share of the active
+        pixels is that small the next batches of the same pixels are traced in the
+        same launches, ahead of the adaptive tests that decide whether they are
+        needed (the tests then run between the batches when the results are
+        summed, and what was traced past a pixel's stop is dropped). The result
+        depends only on counts every rank knows, so all ranks choose alike.
+        """
+        paths = PixelSchedule.padded(n_active_bound, world) * batch
+        k = target_paths // max(paths, 1)
+        k = min(k, max_batches, -(-samples_left // batch))
+        return max(int(k), 1)
+
+
+def render_frame(dev, params, rank=0, world=1, group=None, device=None, record_rounds=None, lag=1,
+                 pixel_stride=1, target_paths=4 << 20, max_batches=32):
     """Renders one frame; returns (hdr[h,w,3], count[h,w]) as tensors on `device`, on every rank.
 
     dev: api.Device with scene and camera set. With world > 1 the default process
@@ -63,6 +81,13 @@ def render_frame(dev, params, rank=0, world=1, group=None, device=None, record_r
     the same on every rank (it is a count, not a timing), so the ranks' collectives
     always agree in size. record_rounds, if a list, receives (samples_done,
     bound, this rank's share of the bound) per round.
+
+    target_paths, max_batches: see PixelSchedule.batches (max_batches = 1 keeps to
+    one batch per round, the reference's own cadence).
+
+    pixel_stride = K renders only every K-th pixel of the rectangle (the others stay
+    black): one GPU then does the work one rank of K would do, which is how the
+    strong-scaling behaviour is rehearsed on a single GPU.
     """
     import torch.distributed as dist
     w, h = params.w, params.h
@@ -75,7 +100,7 @@ def render_frame(dev, params, rank=0, world=1, group=None, device=None, record_r
     x1, y1 = min(w, params.x1), min(h, params.y1)
     ys = torch.arange(y0, y1, device=device, dtype=torch.int32)
     xs = torch.arange(x0, x1, device=device, dtype=torch.int32)
-    bufs = [(ys[:, None] * w + xs[None, :]).reshape(-1).contiguous(), None]
+    bufs = [(ys[:, None] * w + xs[None, :]).reshape(-1)[::max(1, pixel_stride)].contiguous(), None]
     bufs[1] = torch.empty_like(bufs[0])
     n0 = bufs[0].numel()
     n_dev = torch.full((2,), n0, dtype=torch.int64, device=device)  # lengths of bufs[0], bufs[1]
@@ -108,7 +133,9 @@ def render_frame(dev, params, rank=0, world=1, group=None, device=None, record_r
                 bound = min(bound, int(t.item()))
             if bound == 0:
                 break
-        ns = min(params.samples_per_batch, params.ns_aa - done)
+        ns = min(params.samples_per_batch * PixelSchedule.batches(bound, world, params.samples_per_batch,
+                                                                  params.ns_aa - done, target_paths, max_batches),
+                 params.ns_aa - done)
         whole = cabi.PixelList(bufs[cur].data_ptr(), n_dev[cur:].data_ptr(), 0, bound, 0, 1)
         mine = cabi.PixelList(bufs[cur].data_ptr(), n_dev[cur:].data_ptr(), 0, bound, rank, world)
         if record_rounds is not None:

@@ -48,7 +48,11 @@ class OracleDevice:
         rgb = (C.c_double * 3)()
         for px in pix:
             x, y = int(px) % p.w, int(px) // p.w
+            kept = 0
             for s in range(sample_base, sample_base + n_samples):
+                if s > sample_base and s % p.samples_per_batch == 0 and not self._continues(st[px], s, p.max_tolerance):
+                    break
+                kept += 1
                 O.lib().oracle_sample_radiance(C.byref(self.scene.desc), C.byref(self.cam), C.byref(p), x, y, s, rgb)
                 # Vector3D::illum: double arithmetic, float result
                 xl = float(np.float32(float(np.float32(0.2126)) * rgb[0] + float(np.float32(0.7152)) * rgb[1]
@@ -58,8 +62,17 @@ class OracleDevice:
                 st[px, 2] += rgb[0]
                 st[px, 3] += rgb[1]
                 st[px, 4] += rgb[2]
-            st[px, 5] += n_samples
-            self.traced += n_samples
+            st[px, 5] += kept
+            self.traced += kept
+
+    @staticmethod
+    def _continues(row, i, tol):
+        s1, s2 = row[0], row[1]
+        mean = s1 * (1.0 / i)
+        var = (1.0 / (i - 1)) * (s2 - s1 * s1 * (1.0 / i))
+        with np.errstate(invalid="ignore"):
+            conf = 1.96 * np.sqrt(np.float64(var * (1.0 / i)))
+        return not (conf <= tol * mean)
 
     def filter_list(self, pl, n_done, d_state, d_out, d_n_out, stream=0):
         p = self.p
@@ -69,12 +82,7 @@ class OracleDevice:
         k = 0
         i = n_done
         for px in pin:
-            s1, s2 = st[px, 0], st[px, 1]
-            mean = s1 * (1.0 / i)
-            var = (1.0 / (i - 1)) * (s2 - s1 * s1 * (1.0 / i))
-            with np.errstate(invalid="ignore"):
-                conf = 1.96 * np.sqrt(np.float64(var * (1.0 / i)))
-            if not (conf <= p.max_tolerance * mean):
+            if st[px, 5] >= i and self._continues(st[px], i, p.max_tolerance):
                 out[k] = px
                 k += 1
         self._view(d_n_out, 1, np.int64)[0] = k
@@ -133,12 +141,15 @@ def _worker_body(rank, world, port, q):
     dev = OracleDevice(sc, cam)
     p = cabi.make_params(W, H, **KW)
     rounds = []
-    hdr, cnt = distributed.render_frame(dev, p, rank=rank, world=world, device=torch.device("cpu"), record_rounds=rounds,
-                                        lag=0)
+    cpu = torch.device("cpu")
+    hdr, cnt = distributed.render_frame(dev, p, rank=rank, world=world, device=cpu, record_rounds=rounds, lag=0,
+                                        max_batches=1)
     traced = dev.traced
-    # the pipelined schedule (bounds one round old) must give the same frame
-    hdr_l, cnt_l = distributed.render_frame(dev, p, rank=rank, world=world, device=torch.device("cpu"), lag=1)
-    assert torch.equal(hdr_l, hdr) and torch.equal(cnt_l, cnt), "lag=1 frame differs from lag=0"
+    # the pipelined schedule (bounds one round old) must give the same frame, and so
+    # must rounds that trace several batches ahead of their adaptive tests
+    for kw in (dict(lag=1, max_batches=1), dict(lag=1), dict(lag=0, max_batches=2)):
+        hdr_l, cnt_l = distributed.render_frame(dev, p, rank=rank, world=world, device=cpu, **kw)
+        assert torch.equal(hdr_l, hdr) and torch.equal(cnt_l, cnt), "%r: frame differs" % (kw,)
     q.put((rank, hdr.numpy().copy(), cnt.numpy().copy(), rounds, traced))
     dist.barrier()
     dist.destroy_process_group()
@@ -158,11 +169,18 @@ def test_two_ranks_equal_one_rank_bit_for_bit():
     p = cabi.make_params(W, H, **KW)
     one = OracleDevice(sc, cam)
     rounds1 = []
-    hdr1, cnt1 = distributed.render_frame(one, p, device=torch.device("cpu"), record_rounds=rounds1, lag=0)
+    hdr1, cnt1 = distributed.render_frame(one, p, device=torch.device("cpu"), record_rounds=rounds1, lag=0,
+                                          max_batches=1)
     hdr1, cnt1 = hdr1.numpy(), cnt1.numpy()
     rounds_l = []
-    hdr_l, cnt_l = distributed.render_frame(one, p, device=torch.device("cpu"), record_rounds=rounds_l, lag=1)
+    hdr_l, cnt_l = distributed.render_frame(one, p, device=torch.device("cpu"), record_rounds=rounds_l, lag=1,
+                                            max_batches=1)
     assert np.array_equal(hdr_l.numpy(), hdr1) and np.array_equal(cnt_l.numpy(), cnt1)
+    # several batches per round, traced ahead of the adaptive tests: same frame, fewer rounds
+    rounds_s = []
+    hdr_s, cnt_s = distributed.render_frame(one, p, device=torch.device("cpu"), record_rounds=rounds_s, lag=0)
+    assert np.array_equal(hdr_s.numpy(), hdr1) and np.array_equal(cnt_s.numpy(), cnt1)
+    assert len(rounds_s) < len(rounds1)
     # with lag 1 the host's bound of round r is the exact count of round r - 1
     assert [b for _, b, _ in rounds_l[2:]] == [b for _, b, _ in rounds1[1:len(rounds_l) - 1]]
     # the round loop reproduces raytrace_pixel's adaptive loop exactly
@@ -191,6 +209,16 @@ def test_two_ranks_equal_one_rank_bit_for_bit():
     assert t0 + t1 == int(cnt1.sum()) and abs(t0 - t1) <= 16 * len(rounds1)
     for r0, r1 in zip(res[0][3], res[1][3]):
         assert r0[2] + r1[2] == r0[1] and abs(r0[2] - r1[2]) <= 1
+
+
+def test_batches_per_round_policy():
+    B = distributed.PixelSchedule.batches
+    assert B(480000, 1, 32, 1024, 3 << 20, 16) == 1          # a full frame fills the GPU
+    assert B(38000, 1, 32, 700, 3 << 20, 16) == 2            # late rounds of the benchmark frame
+    assert B(38000, 8, 32, 700, 3 << 20, 16) == 16           # the same on 8 GPUs: capped
+    assert B(38000, 8, 32, 96, 3 << 20, 16) == 3             # never past the last sample
+    assert B(100, 1, 32, 1024, 3 << 20, 1) == 1              # the reference's cadence on request
+    assert B(0, 4, 32, 64, 3 << 20, 16) >= 1
 
 
 def test_pixel_schedule_covers_every_pixel_once():

@@ -28,19 +28,27 @@ def _setup(device):
 def test_render_frame_pipelined_equals_synchronous_equals_render(device):
     p = _setup(device)
     cuda = torch.device("cuda", 0)
+    # the reference's cadence: one batch per round, every count read before it is used
+    base_rounds = []
+    hdr_b, cnt_b = distributed.render_frame(device, p, device=cuda, lag=0, max_batches=1, record_rounds=base_rounds)
+    hdr_b, cnt_b = hdr_b.cpu().numpy(), cnt_b.cpu().numpy()
+    assert W * H * 16 < cnt_b.sum() < W * H * 96, "the adaptive test must stop some pixels early"
+    assert len(base_rounds) == 6
+    # ptamd_render and every other schedule (late bounds, batches traced ahead of their tests)
     hdr_r, cnt_r = device.render(p)
-    assert W * H * 16 < cnt_r.sum() < W * H * 96, "the adaptive test must stop some pixels early"
-    for lag in (0, 1, 2):
+    assert np.array_equal(hdr_r, hdr_b) and np.array_equal(cnt_r, cnt_b)
+    assert device.stats().samples == int(cnt_b.sum()), "only the samples that were kept count"
+    for kw in (dict(lag=1, max_batches=1), dict(lag=2, max_batches=1), dict(lag=1), dict(lag=0, max_batches=2),
+               dict(lag=1, max_batches=4, target_paths=200000)):
         rounds = []
-        hdr, cnt = distributed.render_frame(device, p, device=cuda, lag=lag, record_rounds=rounds)
-        assert np.array_equal(hdr.cpu().numpy(), hdr_r) and np.array_equal(cnt.cpu().numpy(), cnt_r), "lag=%d" % lag
+        hdr, cnt = distributed.render_frame(device, p, device=cuda, record_rounds=rounds, **kw)
+        assert np.array_equal(hdr.cpu().numpy(), hdr_b) and np.array_equal(cnt.cpu().numpy(), cnt_b), repr(kw)
         bounds = [b for _, b, _ in rounds]
         assert bounds == sorted(bounds, reverse=True)
-    st = device.stats()
-    assert st.samples == int(cnt_r.sum())
+        assert device.stats().samples == int(cnt_b.sum())
 
 
-def _virtual_ranks_frame(dev, p, world, lag):
+def _virtual_ranks_frame(dev, p, world, lag, max_batches=1, target_paths=3 << 20):
     """render_frame's loop with `world` ranks played in turn on one GPU."""
     cuda = torch.device("cuda", 0)
     npix = p.w * p.h
@@ -62,7 +70,8 @@ def _virtual_ranks_frame(dev, p, world, lag):
                 bound = min(bound, history[len(history) - 1 - lag])
             if bound == 0:
                 break
-        ns = min(p.samples_per_batch, p.ns_aa - done)
+        k = distributed.PixelSchedule.batches(bound, world, p.samples_per_batch, p.ns_aa - done, target_paths, max_batches)
+        ns = min(k * p.samples_per_batch, p.ns_aa - done)
         whole = cabi.PixelList(bufs[cur].data_ptr(), n_dev[cur:].data_ptr(), 0, bound, 0, 1)
         m = distributed.PixelSchedule.padded(bound, world)
         blocks = recv[:world * m]
@@ -82,13 +91,13 @@ def _virtual_ranks_frame(dev, p, world, lag):
     return hdr.view(p.h, p.w, 3).cpu().numpy(), cnt.view(p.h, p.w).cpu().numpy()
 
 
-@pytest.mark.parametrize("world,lag", [(2, 0), (3, 1), (8, 1)])
-def test_virtual_ranks_reproduce_the_single_gpu_frame(device, world, lag):
+@pytest.mark.parametrize("world,lag,max_batches", [(2, 0, 1), (3, 1, 1), (8, 1, 1), (2, 1, 2), (8, 0, 16)])
+def test_virtual_ranks_reproduce_the_single_gpu_frame(device, world, lag, max_batches):
     """Sharding by (offset, stride) + pack / all-gather layout / unpack: bit-identical
     to one GPU for any number of ranks (RNG keys are per pixel and sample)."""
     p = _setup(device)
     hdr_r, cnt_r = device.render(p)
-    hdr, cnt = _virtual_ranks_frame(device, p, world, lag)
+    hdr, cnt = _virtual_ranks_frame(device, p, world, lag, max_batches)
     assert np.array_equal(cnt, cnt_r) and np.array_equal(hdr, hdr_r)
 
 

@@ -2038,7 +2038,9 @@ int ptamd_render(ptamd_context *c, const ptamd_render_params *p, double *hdr_out
     // a round too small to fill the GPU traces several batches per pixel ahead of
     // their adaptive tests (k_accumulate applies them and drops what was not needed)
     const int64_t paths = n_known * p->samples_per_batch;
-    int64_t k = std::max<int64_t>(1, std::min<int64_t>((4 << 20) / std::max<int64_t>(paths, 1), 32));
+    // (most pixels stop at their first test, so the first round traces ahead only when really small)
+    const int64_t target = r == 0 ? (1 << 20) : (4 << 20);
+    int64_t k = std::max<int64_t>(1, std::min<int64_t>(target / std::max<int64_t>(paths, 1), 32));
     const int ns = (int)std::min<int64_t>(k * p->samples_per_batch, p->ns_aa - done);
     rc = ptamd_trace_list(c, &l, done, ns, d_state, s);
     if (rc) { cleanup(); return rc; }

@@ -48,7 +48,7 @@ class PixelSchedule:
         return math.ceil(n_active / world) if n_active else 0
 
     @staticmethod
-    def batches(n_active_bound, world, batch, samples_left, target_paths, max_batches):
+    def batches(n_active_bound, world, batch, samples_left, target_paths, max_batches, first=False):
         """How many batches of `batch` samples a round traces per pixel.
 
         A launch of fewer than `target_paths` paths leaves most of the GPU idle and
@@ -60,6 +60,10 @@ class PixelSchedule:
         depends only on counts every rank knows, so all ranks choose alike.
         """
         paths = PixelSchedule.padded(n_active_bound, world) * batch
+        if first:
+            # most pixels of a typical frame stop at their first test, so the first
+            # round traces ahead only when it is really small
+            target_paths //= 4
         k = target_paths // max(paths, 1)
         k = min(k, max_batches, -(-samples_left // batch))
         return max(int(k), 1)
@@ -134,7 +138,8 @@ def render_frame(dev, params, rank=0, world=1, group=None, device=None, record_r
             if bound == 0:
                 break
         ns = min(params.samples_per_batch * PixelSchedule.batches(bound, world, params.samples_per_batch,
-                                                                  params.ns_aa - done, target_paths, max_batches),
+                                                                  params.ns_aa - done, target_paths, max_batches,
+                                                                  first=(done == 0)),
                  params.ns_aa - done)
         whole = cabi.PixelList(bufs[cur].data_ptr(), n_dev[cur:].data_ptr(), 0, bound, 0, 1)
         mine = cabi.PixelList(bufs[cur].data_ptr(), n_dev[cur:].data_ptr(), 0, bound, rank, world)

@@ -219,6 +219,7 @@ def test_batches_per_round_policy():
     assert B(38000, 8, 32, 96, 3 << 20, 16) == 3             # never past the last sample
     assert B(100, 1, 32, 1024, 3 << 20, 1) == 1              # the reference's cadence on request
     assert B(0, 4, 32, 64, 3 << 20, 16) >= 1
+    assert B(60000, 1, 32, 1024, 4 << 20, 32, first=True) == 1 and B(60000, 1, 32, 1024, 4 << 20, 32) == 2
 
 
 def test_pixel_schedule_covers_every_pixel_once():

@@ -259,8 +259,11 @@ def main():
                              "avg_launch_ms": ms / max(agg["launches"][dom], 1)})
                 if args.scene in ("dragon", "bunny") and (args.width, args.height) == (800, 600):
                     roof["traffic"], roof["traffic_source"] = profiled_traffic(args.scene, names[dom])
-            # whole-frame figure: samples/s x algorithmic bytes per sample
-            b_sample = (ext_rays * b_ext + agg["shadow"] * b_sh + 72 * agg["vertices"]) / max(total_samples, 1) + 16
+            # whole-frame figure: samples/s x algorithmic bytes per sample, the per-sample ray
+            # and vertex counts being the reference traversal's (rays the GPU traced ahead of an
+            # adaptive test and then dropped do not count)
+            sf = c["shadow_fraction"]
+            b_sample = c["rays_per_sample"] * ((1 - sf) * b_ext + sf * b_sh) + 72 * c["vertices_per_sample"] + 16
             roof["bytes_per_sample"] = b_sample
             roof["frame_frac_of_hbm_peak"] = value * b_sample / 1e9 / (HBM_PEAK_GBS * world)
             roof["counts"] = c

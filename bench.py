@@ -39,7 +39,10 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--scene", default="dragon", help="dragon (stand-in), bunny, or a .dae path")
+    ap.add_argument("--scene", default="dragon", help="dragon (stand-in), bunny, spheres, or a .dae path")
+    ap.add_argument("--specular", action="store_true",
+                    help="ideal mirror / glass instead of the reference's black stubs (the divergent-specular "
+                         "stress: --scene spheres --specular --depth 16)")
     ap.add_argument("--width", type=int, default=800)
     ap.add_argument("--height", type=int, default=600)
     ap.add_argument("--spp", type=int, default=None)
@@ -64,6 +67,8 @@ def resolve_scene(name, rank):
         return path, "CBdragon stand-in (CBempty box + 100k-triangle procedural knot; CBdragon.dae is absent from the reference checkout)", 1024
     if name == "bunny":
         return os.path.join(ROOT, "scenes", "CBbunny.dae"), "CBbunny.dae", 256
+    if name == "spheres":
+        return os.path.join(ROOT, "scenes", "CBspheres.dae"), "CBspheres.dae", 1024
     return name, os.path.basename(name), 1024
 
 
@@ -84,7 +89,7 @@ def cpu_leg(scene_path, args, spp, threads_port):
     arr = sc.arrays()
     cam = sc.camera(w, h)
     p = cabi.make_params(w, h, ns_aa=args.cpu_spp, max_ray_depth=args.depth, ns_area_light=args.light_samples,
-                         rect=(cx, 0, cx + cw, h))
+                         rect=(cx, 0, cx + cw, h), specular=args.specular)
     _, _, st = O.render(arr, cam, p, threads=threads_port)
     ext_rays = st.rays - st.shadow_rays
     out["port"] = {"value": st.samples / st.seconds, "cores": threads_port}
@@ -99,7 +104,7 @@ def cpu_leg(scene_path, args, spp, threads_port):
     }
     # the reference itself
     ref = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
-    if os.path.exists(ref):
+    if os.path.exists(ref) and not args.specular:  # the reference only has the black stubs
         tmp = os.path.join(ROOT, "gpurun_out", "bench_ref_cell.ptar")
         os.makedirs(os.path.dirname(tmp), exist_ok=True)
         threads_ref = 8  # the thread count of the reference's own benchmark command line
@@ -169,7 +174,7 @@ def main():
 
     def frame(seed):
         p = cabi.make_params(args.width, args.height, ns_aa=spp, max_ray_depth=args.depth,
-                             ns_area_light=args.light_samples, seed=seed)
+                             ns_area_light=args.light_samples, seed=seed, specular=args.specular)
         hdr, cnt = distributed.render_frame(dev, p, rank=rank, world=world, device=device,
                                             pixel_stride=args.pixel_stride, target_paths=args.target_paths,
                                             max_batches=args.max_batches)
@@ -225,8 +230,9 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "%s %dx%d, %d spp, -l %d -m %d, adaptive 32/0.05" % (
-                workload_name, args.width, args.height, spp, args.light_samples, args.depth),
+            "config": {"workload": "%s %dx%d, %d spp, -l %d -m %d, adaptive 32/0.05%s" % (
+                workload_name, args.width, args.height, spp, args.light_samples, args.depth,
+                ", specular mode" if args.specular else ""),
                 "samples_per_step": total_samples // max(args.steps, 1),
                 "parallelism": "pixels of each adaptive round dealt round-robin over %d GPU(s)" % world},
         }

@@ -68,6 +68,12 @@ typedef struct ptamd_scene_desc {
                                    dim_x, dim_y (3 each), area                         */
   const double *jitter_table;   /* [jitter_n*jitter_n*2] pre-jittered sub-pixel table
                                    (src/pathtracer/sampler.h:78-89)                    */
+  const double *mat_extra;      /* [n_materials*4] or NULL: what the reference parses into
+                                   its specular BSDFs and never uses (bsdf.h MirrorBSDF /
+                                   RefractionBSDF / GlassBSDF fields): glass reflectance rgb,
+                                   ior. mat_param holds mirror reflectance or refraction /
+                                   glass transmittance. Read only when
+                                   ptamd_render_params.specular is set.                  */
 } ptamd_scene_desc;
 
 /* Replaces the Camera fields generate_ray reads (src/pathtracer/camera.cpp:190-203). */
@@ -91,7 +97,30 @@ typedef struct ptamd_render_params {
   int32_t hemisphere;         /* -H direct lighting by uniform hemisphere sampling  */
   double max_tolerance;       /* -a (second word)                                   */
   uint64_t seed;              /* key of the counter-based per-pixel RNG             */
+  int32_t specular;           /* 0: Mirror / Refraction / Glass are the black stubs of
+                                 the reference (advanced_bsdf.cpp:21-27,99-106,124-134).
+                                 1: they are the ideal specular BSDFs those stubs were
+                                 meant to become (see "specular mode" below). No
+                                 counterpart in the reference; not a parity mode.      */
+  int32_t reserved;
 } ptamd_render_params;
+
+/* Specular mode (ptamd_render_params.specular = 1). In the shading frame (z = shading
+ * normal, wo = direction back along the ray):
+ *   reflect(wo)       = (-wo.x, -wo.y, wo.z)
+ *   refract(wo, ior)  : eta = wo.z > 0 ? 1/ior : ior; c2 = 1 - eta^2 (1 - wo.z^2);
+ *                       c2 < 0: total internal reflection; else
+ *                       wi = (-eta wo.x, -eta wo.y, wo.z > 0 ? -sqrt(c2) : sqrt(c2))
+ *   Mirror     : wi = reflect, pdf 1, f = reflectance / |wi.z|
+ *   Refraction : TIR -> f = 0 (path ends); else pdf 1, f = transmittance / |wi.z| / eta^2
+ *   Glass      : TIR -> as Mirror; else R = R0 + (1 - R0)(1 - |wo.z|)^5, R0 = ((1-ior)/(1+ior))^2;
+ *                with probability R: reflect, pdf R, f = R reflectance / |wi.z|;
+ *                else refract, pdf 1 - R, f = (1 - R) transmittance / |wi.z| / eta^2
+ * (the first BSDF random number of the vertex decides). These BSDFs are Dirac deltas:
+ * a vertex on one takes no light samples, and an emitter hit by a ray that left such
+ * a vertex adds its radiance (light sampling could not have accounted for it). In this
+ * mode a vertex whose BSDF is identically zero (an emitter, the microfacet stub) ends
+ * its path. Russian roulette, depth limits and the -o switch work as in the reference. */
 
 typedef struct ptamd_stats {
   double seconds;          /* wall time of the last render (device work only)     */

@@ -83,12 +83,13 @@ typedef struct {
   v3 o, d, inv_d;
   double min_t, max_t; /* max_t is mutated by primitive hits, src/pathtracer/ray.h:26-27 */
   int depth;
+  int via_delta; /* specular mode: the ray left a Dirac-delta BSDF */
 } ray_t;
 static inline ray_t make_ray(v3 o, v3 d) { /* src/pathtracer/ray.h:39-42 */
   ray_t r;
   r.o = o; r.d = d;
   r.inv_d = V(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
-  r.min_t = 0.0; r.max_t = INFINITY; r.depth = 0;
+  r.min_t = 0.0; r.max_t = INFINITY; r.depth = 0; r.via_delta = 0;
   return r;
 }
 typedef struct {
@@ -291,6 +292,68 @@ static v3 bsdf_sample_f(const ctx_t *c, int material, double Xi1, double Xi2, v3
   return bsdf_f(c, material);
 }
 
+/* ---- specular mode (ptamd_render_params.specular; include/ptamd.h states the model).
+ * The reference declares these BSDFs and leaves them empty (advanced_bsdf.cpp:21-27,
+ * 99-106, 124-134, 146-169), so nothing below has a counterpart to be checked against:
+ * parity unpinned. The tests check the formulas analytically and the GPU against this. */
+static int is_delta_kind(int k) { return k == PTAMD_MAT_MIRROR || k == PTAMD_MAT_REFRACTION || k == PTAMD_MAT_GLASS; }
+static v3 reflect_z(v3 wo) { return V(-wo.x, -wo.y, wo.z); }
+static int refract_z(v3 wo, double ior, v3 *wi, double *eta_out) {
+  double eta = wo.z > 0 ? 1.0 / ior : ior;
+  double c2 = 1.0 - eta * eta * (1.0 - wo.z * wo.z);
+  *eta_out = eta;
+  if (c2 < 0) return 0;
+  double cz = sqrt(c2);
+  *wi = V(-eta * wo.x, -eta * wo.y, wo.z > 0 ? -cz : cz);
+  return 1;
+}
+/* Returns f; *wi = (0,0,0) and f = 0 when the path ends (refraction at total
+ * internal reflection). u is the vertex's first BSDF random number. */
+static v3 specular_sample_f(int kind, const double *param3, const double *extra4, v3 wo, double u, v3 *wi, double *pdf) {
+  v3 a = ld3(param3);
+  double ior = extra4 ? extra4[3] : 0.0;
+  double eta;
+  *pdf = 1.0;
+  if (kind == PTAMD_MAT_MIRROR) {
+    *wi = reflect_z(wo);
+    return vdivs(a, fabs(wi->z));
+  }
+  if (kind == PTAMD_MAT_REFRACTION) {
+    if (!refract_z(wo, ior, wi, &eta)) { *wi = V(0, 0, 0); return V(0, 0, 0); }
+    return vdivs(vdivs(a, fabs(wi->z)), eta * eta);
+  }
+  /* glass: a = transmittance, extra = reflectance */
+  v3 refl = extra4 ? ld3(extra4) : V(0, 0, 0);
+  v3 wt;
+  if (!refract_z(wo, ior, &wt, &eta)) {
+    *wi = reflect_z(wo);
+    return vdivs(refl, fabs(wi->z));
+  }
+  double r0 = (1.0 - ior) / (1.0 + ior);
+  r0 = r0 * r0;
+  double m = 1.0 - fabs(wo.z);
+  double R = r0 + (1.0 - r0) * (m * m * m * m * m);
+  if (u < R) {
+    *wi = reflect_z(wo);
+    *pdf = R;
+    return vdivs(vscale(refl, R), fabs(wi->z));
+  }
+  *wi = wt;
+  *pdf = 1.0 - R;
+  return vdivs(vdivs(vscale(a, 1.0 - R), fabs(wi->z)), eta * eta);
+}
+void oracle_kat_specular(int64_t n, const int32_t *kind, const double *param3, const double *extra4, const double *wo,
+                         const double *u, double *wi_out, double *f_out, double *pdf_out) {
+  for (int64_t i = 0; i < n; i++) {
+    v3 wi;
+    double pdf;
+    v3 f = specular_sample_f(kind[i], param3 + 3 * i, extra4 + 4 * i, ld3(wo + 3 * i), u[i], &wi, &pdf);
+    wi_out[3 * i] = wi.x; wi_out[3 * i + 1] = wi.y; wi_out[3 * i + 2] = wi.z;
+    f_out[3 * i] = f.x; f_out[3 * i + 1] = f.y; f_out[3 * i + 2] = f.z;
+    pdf_out[i] = pdf;
+  }
+}
+
 /* SceneLight::sample_L for every light kind (src/scene/light.cpp:17-93) */
 static v3 light_sample_L(const ctx_t *c, int li, v3 p, double sx, double sy, v3 *wi, double *dist, double *pdf) {
   const double *q = c->s->light_param + 16 * (size_t)li;
@@ -441,9 +504,16 @@ static v3 at_least_one_bounce_radiance(ctx_t *c, const rng_t *g, const ray_t *r,
   m3 w2o = mtrans(&o2w);
   v3 hit_p = vadd(r->o, vscale(r->d, isect->t));
   v3 w_out = mmul(&w2o, vneg(r->d));
-  (void)w_out;
   v3 L_out = V(0, 0, 0);
   c->vertices++;
+  const int kind = c->s->mat_kind[isect->material];
+  const int specular = c->p->specular;
+  const int delta = specular && is_delta_kind(kind);
+  if (specular && (kind == PTAMD_MAT_EMISSION || kind == PTAMD_MAT_MICROFACET)) {
+    /* a BSDF that is identically zero ends the path; an emitter reached from a
+     * delta vertex is seen directly (no light sample could have covered it) */
+    return r->via_delta ? bsdf_emission(c, isect->material) : V(0, 0, 0);
+  }
   int max_ray_depth = c->p->max_ray_depth;
   int isAccumBounces = c->p->accumulate_bounces;
   uint32_t base = 1u + (uint32_t)(r->depth - 1) * (uint32_t)c->bpv;
@@ -453,23 +523,31 @@ static v3 at_least_one_bounce_radiance(ctx_t *c, const rng_t *g, const ray_t *r,
   /* the coin is drawn only when the short-circuit reaches it; with a counter-
    * based generator an unread word changes nothing */
   int not_terminate = ignore_RRT || (r->depth < max_ray_depth && (!isAccumBounces || (u[0] < RRT)));
-  if (!not_terminate) return one_bounce_radiance(c, g, r, isect);
+  /* a delta vertex takes no light samples: its BSDF is zero for every sampled direction */
+  if (!not_terminate) return delta ? V(0, 0, 0) : one_bounce_radiance(c, g, r, isect);
 
   v3 wi;
   double pdf;
-  v3 f = bsdf_sample_f(c, isect->material, u[1], u[2], &wi, &pdf);
+  v3 f;
+  if (delta) {
+    const double *extra = c->s->mat_extra ? c->s->mat_extra + 4 * (size_t)isect->material : NULL;
+    f = specular_sample_f(kind, c->s->mat_param + 3 * (size_t)isect->material, extra, w_out, u[1], &wi, &pdf);
+  } else {
+    f = bsdf_sample_f(c, isect->material, u[1], u[2], &wi, &pdf);
+  }
   ray_t bounce_ray = make_ray(hit_p, mmul(&o2w, wi));
   bounce_ray.min_t = EPS_D;
   bounce_ray.depth = r->depth + 1;
+  bounce_ray.via_delta = delta;
   isect_t bounce_isect;
   if (bvh_intersect(c, &bounce_ray, &bounce_isect)) {
     v3 bounce_radiance = at_least_one_bounce_radiance(c, g, &bounce_ray, &bounce_isect);
     /* f * abs_cos_theta(wi) * bounce_radiance / pdf / RRT */
     v3 ind = vdivs(vdivs(vmul(vscale(f, fabs(wi.z)), bounce_radiance), pdf), RRT);
-    if (isAccumBounces) L_out = vadd(one_bounce_radiance(c, g, r, isect), ind);
+    if (isAccumBounces) L_out = delta ? ind : vadd(one_bounce_radiance(c, g, r, isect), ind);
     else L_out = ind;
   } else {
-    L_out = one_bounce_radiance(c, g, r, isect);
+    L_out = delta ? V(0, 0, 0) : one_bounce_radiance(c, g, r, isect);
   }
   return L_out;
 }

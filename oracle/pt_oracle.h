@@ -66,6 +66,11 @@ void oracle_kat_sphere(int64_t n, const double *in /*n*12*/, double *out /*n*6*/
 void oracle_kat_frame(int64_t n, const double *in /*n*3*/, double *out /*n*9*/);
 void oracle_kat_tonemap(int64_t n, const double *in /*n*3*/, int32_t *out /*n*/);
 
+/* The specular-mode BSDFs (include/ptamd.h, "specular mode") on n scripted inputs:
+ * kind, mat_param (3), mat_extra (4), wo (3) and the random number per input. */
+void oracle_kat_specular(int64_t n, const int32_t *kind, const double *param3, const double *extra4, const double *wo,
+                         const double *u, double *wi_out, double *f_out, double *pdf_out);
+
 /* Philox-4x32-10 words, for cross-checking the GPU generator. */
 void oracle_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]);
 

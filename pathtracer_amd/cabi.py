@@ -21,7 +21,7 @@ class SceneDesc(C.Structure):
         ("node_start", _pi32), ("node_count", _pi32),
         ("mat_kind", _pi32), ("mat_param", _pf64),
         ("light_kind", _pi32), ("light_param", _pf64),
-        ("jitter_table", _pf64),
+        ("jitter_table", _pf64), ("mat_extra", _pf64),
     ]
 
 
@@ -35,7 +35,8 @@ class RenderParams(C.Structure):
                 ("x1", C.c_int32), ("y1", C.c_int32), ("ns_aa", C.c_int32),
                 ("max_ray_depth", C.c_int32), ("accumulate_bounces", C.c_int32),
                 ("ns_area_light", C.c_int32), ("samples_per_batch", C.c_int32),
-                ("hemisphere", C.c_int32), ("max_tolerance", C.c_double), ("seed", C.c_uint64)]
+                ("hemisphere", C.c_int32), ("max_tolerance", C.c_double), ("seed", C.c_uint64),
+                ("specular", C.c_int32), ("reserved", C.c_int32)]
 
 
 class PixelList(C.Structure):
@@ -53,7 +54,7 @@ class Stats(C.Structure):
 
 
 def make_params(w, h, ns_aa=1, max_ray_depth=1, accumulate_bounces=True, ns_area_light=1,
-                samples_per_batch=32, max_tolerance=0.05, hemisphere=False, seed=0, rect=None):
+                samples_per_batch=32, max_tolerance=0.05, hemisphere=False, seed=0, rect=None, specular=False):
     """Render parameters with the reference's defaults (application.h:45-66).
 
     max_tolerance goes through float, as the reference's AppConfig field does.
@@ -61,7 +62,7 @@ def make_params(w, h, ns_aa=1, max_ray_depth=1, accumulate_bounces=True, ns_area
     x0, y0, x1, y1 = rect if rect is not None else (0, 0, w, h)
     return RenderParams(w, h, x0, y0, x1, y1, ns_aa, max_ray_depth, int(bool(accumulate_bounces)),
                         ns_area_light, samples_per_batch, int(bool(hemisphere)),
-                        float(np.float32(max_tolerance)), seed)
+                        float(np.float32(max_tolerance)), seed, int(bool(specular)), 0)
 
 
 class SceneArrays:
@@ -71,9 +72,12 @@ class SceneArrays:
               ("prim_material", np.int32), ("node_bbox", np.float64), ("node_left", np.int32),
               ("node_right", np.int32), ("node_start", np.int32), ("node_count", np.int32),
               ("mat_kind", np.int32), ("mat_param", np.float64), ("light_kind", np.int32),
-              ("light_param", np.float64), ("jitter_table", np.float64))
+              ("light_param", np.float64), ("jitter_table", np.float64), ("mat_extra", np.float64))
 
     def __init__(self, arrays, root):
+        arrays = dict(arrays)
+        if "mat_extra" not in arrays:  # dumps of the reference's own scene graph do not carry it
+            arrays["mat_extra"] = np.zeros(4 * np.asarray(arrays["mat_kind"]).size)
         self.a = {k: np.ascontiguousarray(arrays[k], dtype=dt).ravel() for k, dt in self.FIELDS}
         self.root = int(root)
         d = SceneDesc()
@@ -111,6 +115,8 @@ class SceneArrays:
                  mat_param=arr(d.mat_param, d.n_materials * 3, np.float64), light_kind=arr(d.light_kind, d.n_lights, np.int32),
                  light_param=arr(d.light_param, d.n_lights * 16, np.float64),
                  jitter_table=arr(d.jitter_table, d.jitter_n * d.jitter_n * 2, np.float64))
+        if d.mat_extra:
+            a["mat_extra"] = arr(d.mat_extra, d.n_materials * 4, np.float64)
         return cls(a, d.root)
 
 

@@ -25,7 +25,7 @@ struct ptamd_scene {
   StaticScene S;
   // flattened views handed out through ptamd_scene_desc
   std::vector<int32_t> prim_type, prim_material, node_left, node_right, node_start, node_count, mat_kind, light_kind;
-  std::vector<double> prim_pos, prim_nrm, node_bbox, mat_param, light_param, jitter;
+  std::vector<double> prim_pos, prim_nrm, node_bbox, mat_param, mat_extra, light_param, jitter;
 };
 
 extern "C" {
@@ -87,6 +87,9 @@ int ptamd_scene_load(const char *dae_path, ptamd_scene **out) {
     // the three doubles the renderer reads: reflectance / radiance / transmittance
     // (microfacet eta/k/alpha are parsed but unused: its BSDF evaluates to zero)
     s->mat_param.push_back(m.a.x); s->mat_param.push_back(m.a.y); s->mat_param.push_back(m.a.z);
+    // what only the specular mode reads: glass reflectance, index of refraction
+    s->mat_extra.push_back(m.b.x); s->mat_extra.push_back(m.b.y); s->mat_extra.push_back(m.b.z);
+    s->mat_extra.push_back(m.ior);
   }
   for (const Light &l : S.lights) {
     s->light_kind.push_back(l.kind);
@@ -121,6 +124,7 @@ int ptamd_scene_get_desc(const ptamd_scene *s, ptamd_scene_desc *d) {
   d->node_count = s->node_count.data();
   d->mat_kind = s->mat_kind.data();
   d->mat_param = s->mat_param.data();
+  d->mat_extra = s->mat_extra.data();
   d->light_kind = s->light_kind.data();
   d->light_param = s->light_param.data();
   d->jitter_table = s->jitter.data();

@@ -33,13 +33,14 @@ static void usage(const char *binaryName) {
   printf("  -g  <INT>        GPU to render on (default 0)\n");
   printf("  -S  <INT>        Seed of the per-pixel random-number generator (default 0)\n");
   printf("  -C               Count BVH node visits and primitive tests (slower)\n");
+  printf("  -X               Ideal mirror / refraction / glass BSDFs instead of the reference's black stubs\n");
   printf("  -h               Print this help message\n");
   printf("\n");
 }
 
 int main(int argc, char **argv) {
   size_t ns_aa = 1, max_ray_depth = 1, ns_area_light = 1, num_threads = 1, samples_per_batch = 32;
-  bool accumulate = true, hemisphere = false, write_to_file = false, counters = false;
+  bool accumulate = true, hemisphere = false, write_to_file = false, counters = false, specular = false;
   float max_tolerance = 0.05f;
   double lensRadius = 0.0, focalDistance = 4.7;
   size_t w = 0, h = 0, x = (size_t)-1, y = 0, dx = 0, dy = 0;
@@ -47,7 +48,7 @@ int main(int argc, char **argv) {
   unsigned long long seed = 0;
   std::string output_file_name, cam_settings, sceneFilePath;
   int opt;
-  while ((opt = getopt(argc, argv, "s:l:t:m:o:e:hH:f:r:c:b:d:a:p:g:S:C")) != -1) {
+  while ((opt = getopt(argc, argv, "s:l:t:m:o:e:hH:f:r:c:b:d:a:p:g:S:CX")) != -1) {
     switch (opt) {
       case 'f': write_to_file = true; output_file_name = std::string(optarg); break;
       case 'r':
@@ -87,6 +88,7 @@ int main(int argc, char **argv) {
       case 'g': device = atoi(optarg); break;
       case 'S': seed = strtoull(optarg, nullptr, 10); break;
       case 'C': counters = true; break;
+      case 'X': specular = true; break;
       default: usage(argv[0]); return 1;
     }
   }
@@ -110,6 +112,7 @@ int main(int argc, char **argv) {
   RaytracedRenderer renderer(ns_aa, max_ray_depth, accumulate, ns_area_light, 1, 1, 1, num_threads, samples_per_batch,
                              max_tolerance, nullptr, hemisphere, sceneFile, lensRadius, focalDistance, device);
   renderer.pt->seed = seed;
+  renderer.pt->specular = specular;
   renderer.profile_counters = counters;
   // app->resize(w, h) / load_camera (main.cpp:220-224), then set_up_pathtracer
   // (application.cpp:634-640)

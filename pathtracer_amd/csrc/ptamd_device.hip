@@ -75,6 +75,7 @@ struct DevScene {
   const double *prim_nrm;   // [n_prims * 9]
   const int32_t *mat_kind;
   const double *mat_param;
+  const double *mat_extra;  // [n_materials*4] glass reflectance, ior (specular mode)
   const int32_t *light_kind;
   const double *light_param;
   const double *jitter;
@@ -82,7 +83,7 @@ struct DevScene {
 };
 
 struct FrameParams {
-  int32_t w, h, max_ray_depth, accum, ns_area_light, hemisphere, nls, bpv;
+  int32_t w, h, max_ray_depth, accum, ns_area_light, hemisphere, nls, bpv, specular, pad;
   uint32_t seed_lo, seed_hi;
   double tan_h, tan_v, n_clip, f_clip;
   v3 cam_pos;
@@ -711,6 +712,58 @@ __global__ void TRAV_BOUNDS
   }
 }
 
+// Specular mode (ptamd_render_params.specular): the ideal mirror / refraction /
+// glass BSDFs that the reference declares and leaves empty
+// (advanced_bsdf.cpp:21-27, 99-106, 124-134, 146-169); the model is stated in
+// include/ptamd.h. A bounce ray that leaves such a Dirac-delta BSDF carries
+// VIA_DELTA in its path word: an emitter it hits is seen directly.
+constexpr int32_t VIA_DELTA = 1 << 30, PATH_MASK = VIA_DELTA - 1;
+__device__ __forceinline__ bool is_delta_kind(int32_t k) {
+  return k == PTAMD_MAT_MIRROR || k == PTAMD_MAT_REFRACTION || k == PTAMD_MAT_GLASS;
+}
+__device__ __forceinline__ bool refract_z(v3 wo, double ior, v3 &wi, double &eta) {
+  eta = wo.z > 0 ? 1.0 / ior : ior;
+  const double c2 = 1.0 - eta * eta * (1.0 - wo.z * wo.z);
+  if (c2 < 0) return false;
+  const double cz = sqrt(c2);
+  wi = V(-eta * wo.x, -eta * wo.y, wo.z > 0 ? -cz : cz);
+  return true;
+}
+// returns f; wi = 0 and f = 0 when the path ends (refraction at total internal reflection)
+__device__ __forceinline__ v3 specular_sample_f(int32_t kind, const double *a3, const double *e4, v3 wo, double u, v3 &wi,
+                                               double &pdf) {
+  const v3 a = V(a3[0], a3[1], a3[2]);
+  const double ior = e4[3];
+  double eta;
+  pdf = 1.0;
+  if (kind == PTAMD_MAT_MIRROR) {
+    wi = V(-wo.x, -wo.y, wo.z);
+    return vdivs(a, fabs(wi.z));
+  }
+  if (kind == PTAMD_MAT_REFRACTION) {
+    if (!refract_z(wo, ior, wi, eta)) { wi = V(0, 0, 0); return V(0, 0, 0); }
+    return vdivs(vdivs(a, fabs(wi.z)), eta * eta);
+  }
+  const v3 refl = V(e4[0], e4[1], e4[2]);
+  v3 wt;
+  if (!refract_z(wo, ior, wt, eta)) {
+    wi = V(-wo.x, -wo.y, wo.z);
+    return vdivs(refl, fabs(wi.z));
+  }
+  double r0 = (1.0 - ior) / (1.0 + ior);
+  r0 = r0 * r0;
+  const double m = 1.0 - fabs(wo.z);
+  const double R = r0 + (1.0 - r0) * (m * m * m * m * m);
+  if (u < R) {
+    wi = V(-wo.x, -wo.y, wo.z);
+    pdf = R;
+    return vdivs(vscale(refl, R), fabs(wi.z));
+  }
+  wi = wt;
+  pdf = 1.0 - R;
+  return vdivs(vdivs(vscale(a, 1.0 - R), fabs(wi.z)), eta * eta);
+}
+
 // Visibility bytes of consecutive slots, stored four at a time when a vertex's run
 // of slots is word-aligned (nls a multiple of 4).
 struct VisWriter {
@@ -755,12 +808,13 @@ __global__ void __launch_bounds__(256)
     m3 o2w, w2o;
     o2w.c[0] = o2w.c[1] = o2w.c[2] = V(0, 0, 0);
     w2o = o2w;
-    int32_t path = 0;
+    int32_t path = 0, via = 0;
     uint32_t rng_s = 0, rng_pix = 0, rng_base = 0, n_emit = 0;
     if (valid) {
       const uint32_t j = list ? (uint32_t)list[i] : i;
       const int32_t prim = hb.prim[i];
-      path = q.path[j];
+      const int32_t path_word = q.path[j];
+      path = path_word & PATH_MASK;
       if (prim < 0) {
         // bounce ray left the scene: without accumulation the vertex before it
         // keeps its direct light (pathtracer.cpp:196-198)
@@ -803,6 +857,13 @@ __global__ void __launch_bounds__(256)
           if (!fp.accum) { pb.pend[0][path] = 0; pb.pend[1][path] = 0; pb.pend[2][path] = 0; }
         }
         uint8_t flag = 0;
+        const bool delta = fp.specular && is_delta_kind(kind);
+        if (fp.specular && (path_word & VIA_DELTA) && kind == PTAMD_MAT_EMISSION) {
+          // seen through a chain of delta bounces: no light sample could have covered it
+          const v3 E = V(S.mat_param[3 * mat], S.mat_param[3 * mat + 1], S.mat_param[3 * mat + 2]);
+          const v3 val = vmul(T, E);
+          pb.rad[0][path] += val.x; pb.rad[1][path] += val.y; pb.rad[2][path] += val.z;
+        }
         if (fp.max_ray_depth > 0) {
           make_coord_space(o2w, n_sh);
           w2o = mtrans(o2w);
@@ -827,13 +888,21 @@ __global__ void __launch_bounds__(256)
           const bool lit = kind == PTAMD_MAT_DIFFUSE;
           do_nee = lit && nls > 0;
           if (do_nee) flag = 1 | ((!fp.accum && not_terminate) ? 2 : 0);
-          if (not_terminate && lit) {
+          if (not_terminate && (lit || delta)) {
             double pdf;
-            const v3 wi = cosine_sample(u01(wd[1]), u01(wd[2]), pdf);
+            v3 wi;
+            if (delta) {
+              const v3 wo = mmul(w2o, vneg(rd));
+              f = specular_sample_f(kind, S.mat_param + 3 * mat, S.mat_extra + 4 * mat, wo, u01(wd[1]), wi, pdf);
+              push = !(f.x == 0 && f.y == 0 && f.z == 0);
+              via = VIA_DELTA;
+            } else {
+              wi = cosine_sample(u01(wd[1]), u01(wd[2]), pdf);
+              push = true;
+            }
             next_d = mmul(o2w, wi);
             // f * abs_cos_theta(wi) / pdf / RRT, applied to what the rest of the path returns
             next_T = vmul(T, vdivs(vdivs(vscale(f, fabs(wi.z)), pdf), PT_RRT));
-            push = true;
           }
         }
         vb.flag[i] = flag;
@@ -887,7 +956,7 @@ __global__ void __launch_bounds__(256)
     }
     // ---- bounce ray at this entry's position in the next ray arrays
     if (push) {
-      qn.path[i] = path;
+      qn.path[i] = path | via;
       qn.o[0][i] = hit_p.x; qn.o[1][i] = hit_p.y; qn.o[2][i] = hit_p.z;
       qn.d[0][i] = next_d.x; qn.d[1][i] = next_d.y; qn.d[2][i] = next_d.z;
       qn.T[0][i] = next_T.x; qn.T[1][i] = next_T.y; qn.T[2][i] = next_T.z;
@@ -1021,7 +1090,7 @@ __global__ void k_resolve(FrameParams fp, RayQ q, const int32_t *__restrict__ li
         const uint32_t j = list ? (uint32_t)list[i] : i;
         const v3 T = depth == 1 ? V(1, 1, 1) : V(q.T[0][j], q.T[1][j], q.T[2][j]);
         const v3 val = vmul(T, L);
-        const int32_t path = q.path[j];
+        const int32_t path = q.path[j] & PATH_MASK;
         if (flag & 2) {
           pb.pend[0][path] = val.x; pb.pend[1][path] = val.y; pb.pend[2][path] = val.z;
         } else {
@@ -1384,6 +1453,7 @@ int setup_frame_params(ptamd_context *c, const ptamd_render_params *p) {
   fp.accum = p->accumulate_bounces ? 1 : 0;
   fp.ns_area_light = p->ns_area_light;
   fp.hemisphere = p->hemisphere ? 1 : 0;
+  fp.specular = p->specular ? 1 : 0;
   fp.seed_lo = (uint32_t)p->seed;
   fp.seed_hi = (uint32_t)(p->seed >> 32);
   const ptamd_camera &cam = c->cam;
@@ -1688,8 +1758,11 @@ int ptamd_upload_scene(ptamd_context *c, const ptamd_scene_desc *d) {
   std::vector<int32_t> lk(d->light_kind, d->light_kind + d->n_lights);
   std::vector<double> lp(d->light_param, d->light_param + 16 * (size_t)d->n_lights);
   std::vector<double> jt(d->jitter_table, d->jitter_table + 2 * (size_t)d->jitter_n * d->jitter_n);
+  std::vector<double> me(4 * (size_t)d->n_materials, 0.0);
+  if (d->mat_extra) me.assign(d->mat_extra, d->mat_extra + 4 * (size_t)d->n_materials);
   if ((rc = upload(c, mk, &S.mat_kind))) return rc;
   if ((rc = upload(c, mp, &S.mat_param))) return rc;
+  if ((rc = upload(c, me, &S.mat_extra))) return rc;
   if ((rc = upload(c, lk, &S.light_kind))) return rc;
   if ((rc = upload(c, lp, &S.light_param))) return rc;
   if ((rc = upload(c, jt, &S.jitter))) return rc;

@@ -50,6 +50,7 @@ ptamd_render_params PathTracer::make_params(size_t x0, size_t y0, size_t x1, siz
   p.hemisphere = direct_hemisphere_sample ? 1 : 0;
   p.max_tolerance = maxTolerance;
   p.seed = seed;
+  p.specular = specular ? 1 : 0;
   return p;
 }
 

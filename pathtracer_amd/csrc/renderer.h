@@ -56,6 +56,7 @@ class PathTracer {
   double maxTolerance = 0.05f;
   bool direct_hemisphere_sample = false;
   uint64_t seed = 0;  // key of the counter-based RNG (the reference's RNG is unseeded)
+  bool specular = false;  // ideal mirror / refraction / glass instead of the reference's black stubs
 
   // Components (pathtracer.h:87-97): the device context stands in for bvh
   ptamd_context *bvh = nullptr;

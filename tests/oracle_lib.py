@@ -35,6 +35,7 @@ def lib():
         for name in ("oracle_kat_bbox", "oracle_kat_triangle", "oracle_kat_sphere", "oracle_kat_frame"):
             getattr(_LIB, name).argtypes = [C.c_int64, pd, pd]
         _LIB.oracle_kat_tonemap.argtypes = [C.c_int64, pd, pi]
+        _LIB.oracle_kat_specular.argtypes = [C.c_int64, pi, pd, pd, pd, pd, pd, pd, pd]
         _LIB.oracle_philox.argtypes = [C.c_uint32] * 6 + [C.POINTER(C.c_uint32)]
     return _LIB
 
@@ -80,3 +81,16 @@ def philox(c, k):
     out = (C.c_uint32 * 4)()
     lib().oracle_philox(c[0], c[1], c[2], c[3], k[0], k[1], out)
     return list(out)
+
+
+def kat_specular(kind, param3, extra4, wo, u):
+    """The specular-mode BSDFs on scripted inputs: returns (wi[n,3], f[n,3], pdf[n])."""
+    kind = np.ascontiguousarray(kind, np.int32)
+    n = kind.size
+    param3 = np.ascontiguousarray(param3, np.float64).reshape(n, 3)
+    extra4 = np.ascontiguousarray(extra4, np.float64).reshape(n, 4)
+    wo = np.ascontiguousarray(wo, np.float64).reshape(n, 3)
+    u = np.ascontiguousarray(u, np.float64).reshape(n)
+    wi = np.zeros((n, 3)); f = np.zeros((n, 3)); pdf = np.zeros(n)
+    lib().oracle_kat_specular(n, _pi(kind), _pd(param3), _pd(extra4), _pd(wo), _pd(u), _pd(wi), _pd(f), _pd(pdf))
+    return wi, f, pdf

@@ -790,6 +790,9 @@ struct Compact {
 // ray's hit). Restates at_least_one_bounce_radiance (pathtracer.cpp:160-201)
 // iteratively: the path carries its throughput T, every shaded vertex adds
 // T * direct light.
+// (135 VGPRs, 3 waves per SIMD. Forcing 4 waves was measured slower: the kernel is
+// bound by the bytes it moves, about 3.6 TB/s of HBM traffic, not by latency.)
+template <bool HEMI>
 __global__ void __launch_bounds__(256)
     k_shade(FrameParams fp, DevScene S, RayQ q, const int32_t *__restrict__ list, HitBuf hb, RayQ qn, ShadowQ sq,
             VertexBuf vb, PathBuf pb, Compact cp, Ctl *ctl, int32_t depth, PixView pv, uint32_t p0,
@@ -910,11 +913,19 @@ __global__ void __launch_bounds__(256)
       }
       cp.pflag[i] = push ? 1 : 0;
     }
+    // ---- bounce ray at this entry's position in the next ray arrays (first: it frees its registers
+    // for the light-sample loop)
+    if (push) {
+      qn.path[i] = path | via;
+      qn.o[0][i] = hit_p.x; qn.o[1][i] = hit_p.y; qn.o[2][i] = hit_p.z;
+      qn.d[0][i] = next_d.x; qn.d[1][i] = next_d.y; qn.d[2][i] = next_d.z;
+      qn.T[0][i] = next_T.x; qn.T[1][i] = next_T.y; qn.T[2][i] = next_T.z;
+    }
     // ---- light samples into their slots (estimate_direct_lighting_*, pathtracer.cpp:47-135)
     VisWriter vis{vb.vis, (nls & 3) == 0, 0u};
     if (do_nee) {
       int qq = 0;
-      if (!fp.hemisphere) {
+      if (!HEMI) {
         for (int li = 0; li < S.n_lights; li++) {
           const int nsamp = light_is_delta(S.light_kind[li]) ? 1 : fp.ns_area_light;
           for (int jj = 0; jj < nsamp; jj++, qq++) {
@@ -953,13 +964,6 @@ __global__ void __launch_bounds__(256)
       }
     } else if (valid && nls > 0) {
       for (int qq = 0; qq < nls; qq++) vis.put((size_t)i * nls + qq, 0);
-    }
-    // ---- bounce ray at this entry's position in the next ray arrays
-    if (push) {
-      qn.path[i] = path | via;
-      qn.o[0][i] = hit_p.x; qn.o[1][i] = hit_p.y; qn.o[2][i] = hit_p.z;
-      qn.d[0][i] = next_d.x; qn.d[1][i] = next_d.y; qn.d[2][i] = next_d.z;
-      qn.T[0][i] = next_T.x; qn.T[1][i] = next_T.y; qn.T[2][i] = next_T.z;
     }
     // ---- per-block counts for the compaction: wave64 ballot / reduction, then LDS
     const unsigned long long pm = __ballot(push);
@@ -1895,8 +1899,12 @@ int ptamd_trace_list(ptamd_context *c, const ptamd_pixel_list *list, int32_t sam
       else hipLaunchKernelGGL((k_extend<false>), tgrid, tblock, lds, s, c->S, c->q[cur], lst, c->hb, c->ctl, min_t, max_t, gstack);
       L.end();
       L.begin(PTAMD_K_SHADE);
-      hipLaunchKernelGGL(k_shade, ggrid, 256, 0, s, fp, c->S, c->q[cur], lst, c->hb, c->q[cur ^ 1], c->sq, c->vb, pb, c->cp,
-                         c->ctl, depth, pv, up0, sample_base, n_samples);
+      if (fp.hemisphere)
+        hipLaunchKernelGGL(k_shade<true>, ggrid, 256, 0, s, fp, c->S, c->q[cur], lst, c->hb, c->q[cur ^ 1], c->sq, c->vb, pb,
+                           c->cp, c->ctl, depth, pv, up0, sample_base, n_samples);
+      else
+        hipLaunchKernelGGL(k_shade<false>, ggrid, 256, 0, s, fp, c->S, c->q[cur], lst, c->hb, c->q[cur ^ 1], c->sq, c->vb, pb,
+                           c->cp, c->ctl, depth, pv, up0, sample_base, n_samples);
       L.end();
       L.begin(PTAMD_K_OTHER);
       hipLaunchKernelGGL(k_scan2, 1, 1024, 0, s, c->cp, c->ctl);

@@ -121,11 +121,13 @@ def profiled_traffic(scene, kernel):
     """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this
     workload (profiles/, separate FETCH_SIZE and WRITE_SIZE runs). FETCH_SIZE is in KiB and,
     on gfx950, counts 128-byte read requests as 64 bytes, hence the factor 2."""
-    names = {"extend": "k_extend<false>", "shadow": "k_shadow<false, false>", "shade": "k_shade",
+    names = {"extend": "k_extend<false>", "shadow": "k_shadow<false, false>", "shade": "k_shade<false>",
              "resolve": "k_resolve"}
-    path = os.path.join(ROOT, "profiles", "r01b_%s_summary.json" % scene)
-    if kernel not in names or not os.path.exists(path):
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_summary.json" % scene)))
+    if kernel not in names or not found:
         return None, None
+    path = found[-1]  # the latest state profiled
     try:
         d = json.load(open(path))
         f = d["pmc_fetch"][names[kernel]]

@@ -175,6 +175,33 @@ def test_converged_image_agrees_with_reference_at_1024spp(device):
         assert abs(a[..., c].mean() - ref[..., c].mean()) < 0.005 * ref[..., c].mean()
 
 
+@pytest.mark.parametrize("tag,name,w,h,kw", [
+    ("config1_cbsl_480x360_s64_l16_m5", "CBspheres_lambertian", 480, 360, dict(ns_aa=64, ns_area_light=16, max_ray_depth=5)),
+    ("config2_cbbunny_800x600_s256_l4_m5", "CBbunny", 800, 600, dict(ns_aa=256, ns_area_light=4, max_ray_depth=5)),
+])
+def test_benchmark_configurations_agree_with_the_reference(device, tag, name, w, h, kw):
+    """The first two configurations of the benchmark table at full size, against the
+    reference's own render of the same command line (8x8 block means, sample counts).
+    Different random numbers, so the bar is statistical: block means within 2 % relative
+    L2 (they still carry 1/8 of the pixel noise at these sample counts), channel means
+    within 0.5 %, total sample count within 2 %."""
+    g = np.load(os.path.join(GOLDEN, "blocks_%s.npz" % tag))
+    sc = pt.Scene(scene_path(name))
+    device.upload(sc)
+    device.set_camera(sc.camera(w, h))
+    a, ac = device.render(cabi.make_params(w, h, seed=4, **kw))
+    b, _ = device.render(cabi.make_params(w, h, seed=5, **kw))
+    ref = g["hdr_blocks"].astype(np.float64)
+    noise = _rel_l2(_blocks(b), _blocks(a))
+    d = _rel_l2(_blocks(a), ref)
+    assert d < 0.02 and d <= 1.5 * noise + 0.002, (d, noise)
+    assert abs(int(ac.sum()) - int(g["total_samples"])) < 0.02 * int(g["total_samples"])
+    for c in range(3):
+        assert abs(a[..., c].mean() - g["mean_rgb"][c]) < 0.005 * g["mean_rgb"][c]
+    cb = _blocks(ac[..., None].astype(np.float64))[..., 0]
+    assert _rel_l2(cb, g["count_blocks"].astype(np.float64)) < 0.05
+
+
 def test_full_size_frame_properties(device):
     """CBbunny at the benchmark's 800x600 (fewer samples): size-independent invariants."""
     w, h = 800, 600

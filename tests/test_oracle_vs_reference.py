@@ -133,6 +133,30 @@ def test_images_agree_with_reference_within_noise(tag, name, w, h, kw):
     assert abs(imgs[0][1].mean() - refc.mean()) <= 0.03 * refc.mean() + 0.5
 
 
+def test_benchmark_configuration_1_window_agrees_with_the_reference():
+    """`CBspheres_lambertian -s 64 -l 16 -m 5 -r 480 360`, the benchmark table's CPU-sized
+    configuration, rendered by the reference at full size (8x8 block means in the fixture):
+    the restatement renders a 160x120 window of the same frame and must match its blocks."""
+    import pathtracer_amd as pt
+    from conftest import scene_path
+    w, h = 480, 360
+    g = np.load(_g("blocks_config1_cbsl_480x360_s64_l16_m5.npz"))
+    s = pt.Scene(scene_path("CBspheres_lambertian"))
+    arr, cam = s.arrays(), s.camera(w, h)
+    x0, y0, x1, y1 = 160, 96, 320, 216
+    kw = dict(ns_aa=64, ns_area_light=16, max_ray_depth=5, rect=(x0, y0, x1, y1))
+    a, ac, _ = O.render(arr, cam, cabi.make_params(w, h, seed=1, **kw), threads=8)
+    b, _, _ = O.render(arr, cam, cabi.make_params(w, h, seed=2, **kw), threads=8)
+    ref = g["hdr_blocks"].astype(np.float64)[y0 // 8:y1 // 8, x0 // 8:x1 // 8]
+    ba, bb = _blocks(a[y0:y1, x0:x1]), _blocks(b[y0:y1, x0:x1])
+    noise = _rel_l2(bb, ba)
+    d = _rel_l2(ba, ref)
+    assert d < 0.02 and d <= 1.5 * noise + 0.002, (d, noise)
+    refc = g["count_blocks"].astype(np.float64)[y0 // 8:y1 // 8, x0 // 8:x1 // 8]
+    cb = _blocks(ac[y0:y1, x0:x1, None].astype(np.float64))[..., 0]
+    assert abs(cb.mean() - refc.mean()) < 0.03 * refc.mean()
+
+
 def test_black_specular_spheres_like_the_reference():
     """Mirror and glass BSDFs are unfinished stubs in the reference: the spheres render black."""
     g = np.load(_g("render_cbspheres_96x72.npz"))

@@ -114,7 +114,41 @@ def main():
         print("%s: %.1f s, %d samples" % (tag, time.time() - t0, int(a["count"].sum())), flush=True)
 
 
+def blocks(img, b=8):
+    h, w = img.shape[:2]
+    c = img.shape[2] if img.ndim == 3 else 1
+    v = img.reshape(h, w, c)[:h - h % b, :w - w % b].reshape(h // b, b, w // b, b, c).mean(axis=(1, 3))
+    return v if img.ndim == 3 else v[..., 0]
+
+
+def block_goldens():
+    """BASELINE.json's configurations 1 and 2 rendered by the reference at full size; kept as
+    8x8 block means (they keep any bias and little noise) so the fixtures stay small."""
+    sc = scenes()
+    jobs = [
+        ("config1_cbsl_480x360_s64_l16_m5", "CBspheres_lambertian", ["-s", "64", "-l", "16", "-m", "5", "-r", "480", "360"], 480, 360),
+        ("config2_cbbunny_800x600_s256_l4_m5", "CBbunny", ["-s", "256", "-l", "4", "-m", "5", "-r", "800", "600"], 800, 600),
+    ]
+    for tag, name, args, w, h in jobs:
+        out = os.path.join(TMP, "b.ptar")
+        t0 = time.time()
+        run(["render"] + args + ["-t", "8", "-f", out, sc[name]])
+        a = ptar.load(out)
+        hdr = a["hdr"].reshape(h, w, 3)
+        cnt = a["count"].reshape(h, w).astype(np.float64)
+        np.savez_compressed(os.path.join(GOLD, "blocks_%s.npz" % tag), hdr_blocks=blocks(hdr).astype(np.float32),
+                            count_blocks=blocks(cnt).astype(np.float32), total_samples=np.int64(a["count"].sum()),
+                            mean_rgb=hdr.reshape(-1, 3).mean(axis=0),
+                            cmd=np.array(" ".join(["ref_driver", "render"] + args + ["-t", "8", name + ".dae"])))
+        print("%s: %.1f s, %d samples" % (tag, time.time() - t0, int(a["count"].sum())), flush=True)
+
+
 if __name__ == "__main__":
     if not os.path.exists(REF):
         raise SystemExit("build the reference driver first: make -C oracle ref")
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "blocks":
+        os.makedirs(TMP, exist_ok=True)
+        block_goldens()
+    else:
+        main()
+        block_goldens()

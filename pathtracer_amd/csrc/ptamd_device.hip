@@ -1066,21 +1066,25 @@ __global__ void k_resolve(FrameParams fp, RayQ q, const int32_t *__restrict__ li
   for (uint32_t base_i = blockIdx.x * blockDim.x; base_i < n; base_i += stride) {
     const uint32_t i = base_i + threadIdx.x;
     if (i < n) {
+      // Loads that do not depend on each other are issued together: the kernel does
+      // almost no arithmetic, its time is the chain of memory round trips.
       const uint8_t flag = vb.flag[i];
+      const uint32_t j = list ? (uint32_t)list[i] : i;
       if (flag) {
         verts++;
+        const int32_t path = q.path[j] & PATH_MASK;
+        const v3 T = depth == 1 ? V(1, 1, 1) : V(q.T[0][j], q.T[1][j], q.T[2][j]);
         v3 L = V(0, 0, 0);
         const size_t b = (size_t)i * nls;
         if ((nls & 3) == 0) {
           for (int q4 = 0; q4 < nls; q4 += 4) {
             const uint32_t vw = *reinterpret_cast<const uint32_t *>(vb.vis + b + q4);
+            Contrib cc[4];
 #pragma unroll
-            for (int qq = 0; qq < 4; qq++) {
-              if (((vw >> (8 * qq)) & 0xffu) == 1u) {
-                const Contrib cc = vb.contrib[b + q4 + qq];
-                L = vadd(L, V(cc.c[0], cc.c[1], cc.c[2]));
-              }
-            }
+            for (int qq = 0; qq < 4; qq++) cc[qq] = vb.contrib[b + q4 + qq];  // whether visible or not
+#pragma unroll
+            for (int qq = 0; qq < 4; qq++)
+              if (((vw >> (8 * qq)) & 0xffu) == 1u) L = vadd(L, V(cc[qq].c[0], cc[qq].c[1], cc[qq].c[2]));
           }
         } else {
           for (int qq = 0; qq < nls; qq++) {
@@ -1091,10 +1095,7 @@ __global__ void k_resolve(FrameParams fp, RayQ q, const int32_t *__restrict__ li
           }
         }
         L = vscale(L, 1. / (double)nls);
-        const uint32_t j = list ? (uint32_t)list[i] : i;
-        const v3 T = depth == 1 ? V(1, 1, 1) : V(q.T[0][j], q.T[1][j], q.T[2][j]);
         const v3 val = vmul(T, L);
-        const int32_t path = q.path[j] & PATH_MASK;
         if (flag & 2) {
           pb.pend[0][path] = val.x; pb.pend[1][path] = val.y; pb.pend[2][path] = val.z;
         } else {

@@ -1,16 +1,19 @@
 // Device layer of the render hot path for MI355X (gfx950): a wavefront path
-// tracer. One frame is rendered in rounds of `samples_per_batch` samples per
-// still-active pixel; each round runs, per path depth,
+// tracer. One frame is rendered in rounds of one or more batches of
+// `samples_per_batch` samples per still-active pixel; each round runs, per path
+// depth,
 //
-//   extend   closest-hit BVH traversal of the ray queue      (BVHAccel::intersect)
-//   shade    emission, Russian roulette, BSDF sample, NEE    (at_least_one_bounce_radiance,
-//            sample generation; wave64 ballot/prefix appends  estimate_direct_lighting_*)
-//   shadow   any-hit traversal of the shadow-ray queue
+//   extend   closest-hit BVH traversal of the ray list       (BVHAccel::intersect)
+//   shade    emission, Russian roulette, BSDF sample, light   (at_least_one_bounce_radiance,
+//            samples into fixed slots; per-block counts        estimate_direct_lighting_*)
+//   scan2, scatter   ordered compaction: next ray list, shadow-ray list
+//   shadow   any-hit traversal of the shadow-ray list
 //   resolve  ordered sum of the unoccluded light samples
 //
 // and finally `accumulate` folds the finished paths into the per-pixel sums in
-// sample order, exactly as PathTracer::raytrace_pixel does
-// (src/pathtracer/pathtracer.cpp:234-272 of the reference).
+// sample order, applying the adaptive test between batches, exactly as
+// PathTracer::raytrace_pixel does (src/pathtracer/pathtracer.cpp:234-272 of the
+// reference).
 //
 // All arithmetic that decides a result is FP64 in the reference's operation
 // order and this file is compiled with -ffp-contract=off. Queue sizes live on
@@ -561,10 +564,9 @@ __global__ void k_set_counts(Ctl *ctl, PixView pv, uint32_t p0, uint32_t chunk, 
 
 // end of one depth: fold the stage's counts into the statistics, make the next
 // queue current
-__global__ void k_advance(Ctl *ctl, int count_vertices) {
+__global__ void k_advance(Ctl *ctl) {
   ctl->st_rays += (unsigned long long)ctl->n_cur + ctl->n_shadow;
   ctl->st_shadow += ctl->n_shadow;
-  (void)count_vertices;
   ctl->n_cur = ctl->n_next;
   ctl->n_next = 0;
   ctl->n_shadow = 0;
@@ -1923,11 +1925,11 @@ int ptamd_trace_list(ptamd_context *c, const ptamd_pixel_list *list, int32_t sam
         L.end();
         L.begin(PTAMD_K_RESOLVE);
         hipLaunchKernelGGL(k_resolve, ggrid, 256, 0, s, fp, c->q[cur], lst, c->vb, pb, c->ctl, depth);
-        hipLaunchKernelGGL(k_advance, 1, 1, 0, s, c->ctl, 1);
+        hipLaunchKernelGGL(k_advance, 1, 1, 0, s, c->ctl);
         L.end();
       } else {
         L.begin(PTAMD_K_OTHER);
-        hipLaunchKernelGGL(k_advance, 1, 1, 0, s, c->ctl, 1);
+        hipLaunchKernelGGL(k_advance, 1, 1, 0, s, c->ctl);
         L.end();
       }
       cur ^= 1;

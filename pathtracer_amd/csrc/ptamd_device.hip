@@ -1288,7 +1288,7 @@ struct ptamd_context {
   ptamd_render_params params{};
   FrameParams fp{};
   // work buffers
-  int64_t max_paths = 4 << 20;
+  int64_t max_paths = 16 << 20;  // paths per launch: large launches amortise the drain of the slowest waves
   int64_t cap_paths = 0;
   int cap_nls = 0;
   bool cap_pend = false;
@@ -1517,7 +1517,7 @@ void ptamd_destroy(ptamd_context *c) {
 
 int ptamd_set_max_paths(ptamd_context *c, int64_t max_paths) {
   if (!c) { ptamd::set_error("null context"); return PTAMD_ERR_ARG; }
-  if (max_paths <= 0) max_paths = 4 << 20;
+  if (max_paths <= 0) max_paths = 16 << 20;
   if (max_paths > ((int64_t)1 << 27)) max_paths = (int64_t)1 << 27;
   c->max_paths = max_paths;
   return PTAMD_OK;
@@ -2123,7 +2123,7 @@ int ptamd_render(ptamd_context *c, const ptamd_render_params *p, double *hdr_out
     // their adaptive tests (k_accumulate applies them and drops what was not needed)
     const int64_t paths = n_known * p->samples_per_batch;
     // (most pixels stop at their first test, so the first round traces ahead only when really small)
-    const int64_t target = r == 0 ? (1 << 20) : (4 << 20);
+    const int64_t target = r == 0 ? (4 << 20) : (16 << 20);
     int64_t k = std::max<int64_t>(1, std::min<int64_t>(target / std::max<int64_t>(paths, 1), 32));
     const int ns = (int)std::min<int64_t>(k * p->samples_per_batch, p->ns_aa - done);
     rc = ptamd_trace_list(c, &l, done, ns, d_state, s);

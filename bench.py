@@ -51,7 +51,7 @@ def parse_args():
     ap.add_argument("--max-paths", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-spp", type=int, default=256)
-    ap.add_argument("--target-paths", type=int, default=4 << 20, help="see PixelSchedule.batches")
+    ap.add_argument("--target-paths", type=int, default=16 << 20, help="see PixelSchedule.batches")
     ap.add_argument("--max-batches", type=int, default=32)
     ap.add_argument("--pixel-stride", type=int, default=1,
                     help="rehearsal: render every K-th pixel only, i.e. the work of one rank of K")

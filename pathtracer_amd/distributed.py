@@ -70,7 +70,7 @@ class PixelSchedule:
 
 
 def render_frame(dev, params, rank=0, world=1, group=None, device=None, record_rounds=None, lag=1,
-                 pixel_stride=1, target_paths=4 << 20, max_batches=32):
+                 pixel_stride=1, target_paths=16 << 20, max_batches=32):
     """Renders one frame; returns (hdr[h,w,3], count[h,w]) as tensors on `device`, on every rank.
 
     dev: api.Device with scene and camera set. With world > 1 the default process

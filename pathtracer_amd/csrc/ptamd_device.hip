@@ -1870,7 +1870,10 @@ int ptamd_trace_list(ptamd_context *c, const ptamd_pixel_list *list, int32_t sam
   hipStream_t s = (hipStream_t)stream;
   const FrameParams &fp = c->fp;
   const int nls = std::max(fp.nls, 1);
-  int64_t px_per_chunk = std::max<int64_t>(1, c->max_paths / n_samples);
+  // paths per launch: max_paths, but never more than a 24 GB slab of work buffers
+  // (about 290 bytes per path + 70 per light-sample slot)
+  const int64_t by_memory = ((int64_t)24 << 30) / (290 + 70 * (int64_t)nls);
+  int64_t px_per_chunk = std::max<int64_t>(1, std::min(c->max_paths, by_memory) / n_samples);
   px_per_chunk = std::min(px_per_chunk, n);
   rc = ensure_buffers(c, px_per_chunk * n_samples, nls, !fp.accum);
   if (rc) return rc;

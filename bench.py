@@ -244,6 +244,21 @@ def main():
                 cpu = cpu_leg(scene_path, args, spp, threads_port=min(16, os.cpu_count() or 1))
             except Exception as e:  # the baseline must never take the GPU number down with it
                 cpu = {"error": repr(e)}
+        # ---- the GPU walk's own work per ray (untimed extra frame with the traversal counters on)
+        own = None
+        if world == 1:
+            try:
+                dev.set_profiling(events=False, counters=True)
+                pc = cabi.make_params(args.width, args.height, ns_aa=min(spp, 64), max_ray_depth=args.depth,
+                                      ns_area_light=args.light_samples, seed=77, specular=args.specular)
+                distributed.render_frame(dev, pc, device=device, pixel_stride=args.pixel_stride)
+                sc_ = dev.stats()
+                if sc_.rays:
+                    own = {"nodes_per_ray": sc_.nodes_visited / 4.0 / sc_.rays, "prims_per_ray": sc_.prim_tests / sc_.rays}
+                    # its records: 64-byte 4-wide node, 80-byte primitive, the same 92 bytes of ray and hit
+                    own["bytes_per_ray"] = 64 * own["nodes_per_ray"] + 80 * own["prims_per_ray"] + 92
+            except Exception as e:
+                own = {"error": repr(e)}
         # ---- roofline of the dominant kernel (rank 0's launches)
         names = cabi.K_NAMES
         dom = max(range(8), key=lambda k: agg["ms"][k])
@@ -265,6 +280,10 @@ def main():
                              "bytes_per_ray": b, "rays_per_launch": rays / max(agg["launches"][dom], 1),
                              "algorithmic_bytes_per_launch": rays * b / max(agg["launches"][dom], 1),
                              "avg_launch_ms": ms / max(agg["launches"][dom], 1)})
+                if own and "bytes_per_ray" in own and ach:
+                    # the same launches priced by what the GPU walk itself fetches (all rays averaged)
+                    own["achieved"] = ach * own["bytes_per_ray"] / b
+                    own["frac"] = own["achieved"] / HBM_PEAK_GBS
                 if args.scene in ("dragon", "bunny") and (args.width, args.height) == (800, 600):
                     roof["traffic"], roof["traffic_source"] = profiled_traffic(args.scene, names[dom])
             # whole-frame figure: samples/s x algorithmic bytes per sample, the per-sample ray
@@ -275,6 +294,8 @@ def main():
             roof["bytes_per_sample"] = b_sample
             roof["frame_frac_of_hbm_peak"] = value * b_sample / 1e9 / (HBM_PEAK_GBS * world)
             roof["counts"] = c
+        if own:
+            roof["gpu_walk"] = own
         line["roofline"] = roof
         if cpu and "reference" in cpu:
             line["cpu_baseline"] = {"value": cpu["reference"]["value"], "unit": "samples/s",

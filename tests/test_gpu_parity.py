@@ -53,6 +53,10 @@ CASES = [
     ("CBgems", 64, 48, dict(ns_aa=32, max_ray_depth=4, ns_area_light=2)),
     ("CBbunny", 80, 60, dict(ns_aa=32, max_ray_depth=5, ns_area_light=4)),
     ("cube", 48, 36, dict(ns_aa=16, max_ray_depth=3, ns_area_light=2)),
+    ("CBspheres_lambertian", 64, 48, dict(ns_aa=32, max_ray_depth=3, ns_area_light=4, hemisphere=True)),
+    ("CBspheres_lambertian", 64, 48, dict(ns_aa=32, max_ray_depth=2, ns_area_light=2, hemisphere=True, accumulate_bounces=False)),
+    ("CBempty", 64, 48, dict(ns_aa=32, max_ray_depth=4, ns_area_light=4)),
+    ("CBcoil", 64, 48, dict(ns_aa=16, max_ray_depth=5, ns_area_light=2)),
 ]
 
 
@@ -73,12 +77,55 @@ def test_render_matches_oracle(device, name, w, h, kw):
     rh, rc, st = O.render(arr, cam, p, threads=8)
     assert cnt.sum() > 0
     same_cnt = (cnt == rc).mean()
-    assert same_cnt >= 0.999, "sample-count maps differ on %.3f%% of pixels" % (100 * (1 - same_cnt))
-    close = np.isclose(hdr, rh, rtol=1e-9, atol=1e-12).all(axis=2)
-    assert close.mean() >= 0.999, "%.3f%% of pixels differ beyond rounding" % (100 * (1 - close.mean()))
-    assert _rel_l2(hdr, rh) < 1e-3
+    # The uniform hemisphere sampler evaluates sinf / cosf in FLOAT, as the reference does
+    # (src/pathtracer/sampler.cpp:35-49); the device's and glibc's float routines differ in
+    # the last bit, so with -H (and the infinite hemisphere light) directions agree to
+    # ~1e-7 only, and a grazing sample can change sides of an edge.
+    float_trig = bool(kw.get("hemisphere"))
+    rtol, share = (2e-5, 0.97) if float_trig else (1e-9, 0.999)
+    assert same_cnt >= share, "sample-count maps differ on %.3f%% of pixels" % (100 * (1 - same_cnt))
+    close = np.isclose(hdr, rh, rtol=rtol, atol=1e-12).all(axis=2)
+    assert close.mean() >= share, "%.3f%% of pixels differ beyond rounding" % (100 * (1 - close.mean()))
+    assert _rel_l2(hdr, rh) < (2e-2 if float_trig else 1e-3)
     gs = device.stats()
     assert gs.samples == st.samples or same_cnt < 1.0
+
+
+@pytest.mark.parametrize("kind,param", [
+    # kind, (radiance, position, direction, dim_x, dim_y, area)
+    (0, ([2.0, 1.8, 1.5], [0, 0, 0], [0.3, -0.2, -1.0], [0, 0, 0], [0, 0, 0], 0)),     # directional
+    (1, ([0.8, 0.9, 1.0], [0, 0, 0], [0, 0, 0], [0, 0, 0], [0, 0, 0], 0)),             # infinite hemisphere
+    (2, ([3.0, 3.0, 3.0], [0.1, 0.2, 1.2], [0, 0, 0], [0, 0, 0], [0, 0, 0], 0)),       # point
+    (3, ([3.0, 3.0, 3.0], [0.1, 0.2, 1.2], [0, 0, -1], [0, 0, 0], [0, 0, 0], 0)),      # spot: a stub that emits nothing
+])
+def test_every_light_kind_matches_oracle(device, kind, param):
+    """The Cornell box with its area light swapped for each other kind of light
+    (src/scene/light.cpp:17-93), alone and next to the area light."""
+    w, h = 64, 48
+    sc, arr, cam = _load("CBspheres_lambertian", w, h)
+    rec = np.concatenate([np.asarray(v, np.float64).ravel() for v in param[:5]] + [np.array([float(param[5])])])
+    assert rec.size == 16
+    for keep_area in (False, True):
+        a = dict(arr.a)
+        if keep_area:
+            a["light_kind"] = np.concatenate([arr.a["light_kind"], [kind]]).astype(np.int32)
+            a["light_param"] = np.concatenate([arr.a["light_param"], rec])
+        else:
+            a["light_kind"] = np.array([kind], np.int32)
+            a["light_param"] = rec
+        mod = cabi.SceneArrays(a, arr.root)
+        device.upload(mod)
+        device.set_camera(cam)
+        p = cabi.make_params(w, h, ns_aa=16, max_ray_depth=3, ns_area_light=2, seed=21)
+        hdr, cnt = device.render(p)
+        rh, rc, _ = O.render(mod, cam, p, threads=8)
+        # the infinite hemisphere light samples with float trigonometry (see test_render_matches_oracle)
+        rtol, share = (2e-5, 0.97) if kind == 1 else (1e-9, 0.999)
+        assert (cnt == rc).mean() >= share
+        close = np.isclose(hdr, rh, rtol=rtol, atol=1e-12).all(axis=2)
+        assert close.mean() >= share, "kind %d keep_area %s: %.3f%% differ" % (kind, keep_area, 100 * (1 - close.mean()))
+        if keep_area or kind == 2:  # lights at infinity alone cannot reach into the closed box
+            assert hdr.max() > 0
 
 
 def test_render_rectangle_only(device):

@@ -159,6 +159,30 @@ def test_small_max_paths_chunks_identically(device):
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
 
 
+def test_edge_shapes(device):
+    """Empty and tiny work: an empty rectangle, a one-pixel frame, fewer samples than a batch,
+    a batch larger than the sample budget, depth 0."""
+    sc, arr, cam = _load("CBspheres_lambertian", 32, 24)
+    device.upload(sc)
+    device.set_camera(cam)
+    hdr, cnt = device.render(cabi.make_params(32, 24, ns_aa=4, rect=(5, 5, 5, 9)))
+    assert not hdr.any() and not cnt.any()
+    hdr, cnt = device.render(cabi.make_params(32, 24, ns_aa=4, rect=(40, 0, 50, 10)))   # outside the frame
+    assert not hdr.any() and not cnt.any()
+    for kw in (dict(ns_aa=3, samples_per_batch=32), dict(ns_aa=5, samples_per_batch=2, max_tolerance=0.5),
+               dict(ns_aa=1, max_ray_depth=0), dict(ns_aa=33, samples_per_batch=32, max_ray_depth=2, ns_area_light=1)):
+        p = cabi.make_params(32, 24, seed=2, **kw)
+        hdr, cnt = device.render(p)
+        rh, rc, _ = O.render(arr, cam, p, threads=4)
+        assert np.array_equal(cnt, rc) and np.allclose(hdr, rh, rtol=1e-9, atol=1e-12), kw
+    one = pt.Scene(scene_path("CBspheres_lambertian"))
+    device.set_camera(one.camera(1, 1))
+    p = cabi.make_params(1, 1, ns_aa=8, max_ray_depth=2, ns_area_light=2)
+    hdr, cnt = device.render(p)
+    rh, rc, _ = O.render(arr, one.camera(1, 1), p, threads=1)
+    assert np.array_equal(cnt, rc) and np.allclose(hdr, rh, rtol=1e-9, atol=1e-12)
+
+
 def test_errors_are_reported_not_fatal(device):
     with pytest.raises(pt.PtamdError):
         pt.Scene("/nonexistent/scene.dae")

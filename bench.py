@@ -152,6 +152,9 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
+    # one rank per GPU; if the launcher masks devices so that each rank sees only its own,
+    # LOCAL_RANK no longer names a visible device
+    local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:

@@ -53,6 +53,8 @@ def parse_args():
     ap.add_argument("--cpu-spp", type=int, default=256)
     ap.add_argument("--target-paths", type=int, default=16 << 20, help="see PixelSchedule.batches")
     ap.add_argument("--max-batches", type=int, default=32)
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL; the real thing) or gloo (rehearsal of the "
+                    "multi-rank flow with several ranks on one GPU, rows staged through the host)")
     ap.add_argument("--pixel-stride", type=int, default=1,
                     help="rehearsal: render every K-th pixel only, i.e. the work of one rank of K")
     return ap.parse_args()
@@ -159,7 +161,10 @@ def main():
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     scene_path, workload_name, default_spp = resolve_scene(args.scene, rank)
     spp = args.spp or default_spp
@@ -215,7 +220,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

@@ -151,7 +151,13 @@ def render_frame(dev, params, rank=0, world=1, group=None, device=None, record_r
             m = PixelSchedule.padded(bound, world)
             send, recv = rows_send[:m], rows_recv[:world * m]
             dev.pack_rows(mine, state.data_ptr(), send.data_ptr(), stream)
-            dist.all_gather_into_tensor(recv, send, group=group)
+            if on_gpu and dist.get_backend(group) == "gloo":
+                # rehearsal without RCCL (several ranks sharing one GPU): stage through the host
+                got = torch.empty(recv.shape, dtype=recv.dtype)
+                dist.all_gather_into_tensor(got, send.cpu(), group=group)
+                recv.copy_(got)
+            else:
+                dist.all_gather_into_tensor(recv, send, group=group)
             dev.unpack_rows(whole, world, rank, recv.data_ptr(), m, state.data_ptr(), stream)
         done += ns
     hdr = torch.empty(npix * 3, dtype=torch.float64, device=device)

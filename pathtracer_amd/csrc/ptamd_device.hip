@@ -95,6 +95,7 @@ struct FrameParams {
 
 struct Ctl {
   uint32_t n_cur, n_next, n_shadow, n_pix;  // sizes of the ray lists; pixels of the running chunk
+  uint32_t grab[4];  // next unclaimed ray of the running extend / shadow kernel (persistent driver)
   unsigned long long st_rays, st_shadow, st_vertices, st_nodes, st_tests, st_samples;
 };
 
@@ -223,11 +224,20 @@ constexpr int STACK_LDS = PTAMD_STACK_LDS;
 #ifndef PTAMD_NODE_STEPS
 #define PTAMD_NODE_STEPS 2
 #endif
-#if PTAMD_WAVES_PER_EU > 0
-#define TRAV_BOUNDS __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PTAMD_WAVES_PER_EU, PTAMD_WAVES_PER_EU)))
-#else
-#define TRAV_BOUNDS __launch_bounds__(256)
+// idle lanes at which a persistent wave refills (0: grid-stride driver), see trace_rays
+#ifndef PTAMD_REFILL_EXTEND
+#define PTAMD_REFILL_EXTEND 16
 #endif
+#ifndef PTAMD_REFILL_SHADOW
+#define PTAMD_REFILL_SHADOW 32
+#endif
+#ifndef PTAMD_WAVES_EXTEND
+#define PTAMD_WAVES_EXTEND 5  // the closest-hit walk with lane refill needs ~96 registers; spilling costs more than a wave
+#endif
+#ifndef PTAMD_WAVES_SHADOW
+#define PTAMD_WAVES_SHADOW PTAMD_WAVES_PER_EU
+#endif
+#define TRAV_BOUNDS_N(n) __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(n, n)))
 constexpr int TRAV_BLOCK = 256;
 struct TravStack {
   uint2 *lds;
@@ -429,43 +439,103 @@ struct Walk {
   }
 };
 
-// Traces a list of rays, one ray per lane per grid-stride step. Policy:
-// load(i, o, d, min_t, max_t) reads ray i; store(i, hit, found) writes its result.
+// Traces a list of rays. Policy: load(i, o, d, min_t, max_t) reads ray i;
+// store(i, hit, found) writes its result. One trip of the walk: PTAMD_NODE_STEPS
+// box steps for the lanes at a node, then a primitive test for the lanes at a
+// primitive (which includes lanes a box step just brought there). Running the two
+// kinds of step one after the other, instead of one kind per trip, keeps more
+// lanes busy per instruction.
 //
-// Measured on MI355X and rejected:
-//  * persistent waves that hand finished lanes a new ray (refilling at once, or
-//    once 16 / 32 / 48 lanes are idle): 1.6x to 1.9x slower although a wave's
-//    slowest ray takes about three times the average number of trips. Lanes that
-//    start together share the top of the tree (one cache line serves the wave);
-//    refilled lanes are everywhere in the tree at once and every trip waits for
-//    an L2 access;
-//  * sorting each workgroup's 256 rays by direction octant: no gain;
-//  * one box step or one primitive test per trip (if / else), or box steps until
-//    every lane has a primitive (while-while): 5 % and 25 % slower.
-template <bool ANY, bool COUNT, class Policy>
-__device__ __forceinline__ void trace_rays(const DevScene &S, const Policy &pol, uint32_t n, const TravStack &stack,
-                                           uint32_t &n_nodes, uint32_t &n_tests) {
+// Two drivers:
+//  REFILL == 0: one ray per lane per grid-stride step; the wave waits for its
+//    slowest ray (which takes about three times the average number of trips).
+//  REFILL > 0: persistent waves. A wave claims rays in chunks of GRAB from a
+//    counter shared by the launch, and once REFILL of its lanes are idle they are
+//    given the next rays. Which lane traces a ray does not affect where its
+//    result is stored. Lanes that start together share the top of the tree (one
+//    cache line serves the wave) while refilled lanes are all over it, and the
+//    bookkeeping costs registers: measured on MI355X this wins for shadow rays
+//    (coherent: they converge on the light; -18 % on CBbunny) and loses for
+//    bounce rays (+5 to +15 %), so each kernel picks its driver.
+//
+// Also measured and rejected: sorting each workgroup's 256 rays by direction
+// octant (no gain); one box step or one primitive test per trip (if / else),
+// or box steps until every lane has a primitive (while-while): 5 % and 25 %
+// slower; cutting the list into one contiguous band per XCD so that each XCD's
+// L2 holds only its band's share of the scene: 12 % slower (the bands differ in
+// cost and the XCDs with easy bands idle).
+#ifndef PTAMD_GRAB
+#define PTAMD_GRAB 256
+#endif
+template <bool ANY, bool COUNT, int REFILL, class Policy>
+__device__ __forceinline__ void trace_rays(const DevScene &S, const Policy &pol, uint32_t n, uint32_t *grab,
+                                           const TravStack &stack, uint32_t &n_nodes, uint32_t &n_tests) {
   Walk w;
-  // (Cutting the list into one contiguous band per XCD, so that each XCD's L2
-  // would hold only its band's share of the scene, was measured 12 % slower: the
-  // bands differ in cost and the XCDs with easy bands idle.)
-  const uint32_t stride = gridDim.x * blockDim.x;
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    v3 o, d;
-    double tmin, tmax;
-    pol.load(i, o, d, tmin, tmax);
-    w.begin(S, o, d, tmin, tmax);
-    // One trip: PTAMD_NODE_STEPS box steps for the lanes at a node, then a
-    // primitive test for the lanes at a primitive (which includes lanes a box step
-    // just brought there). Running the two kinds of step one after the other,
-    // instead of one kind per trip, keeps more lanes busy per instruction.
-    while (w.cur != CHILD_EMPTY) {
+  if (REFILL == 0) {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+      v3 o, d;
+      double tmin, tmax;
+      pol.load(i, o, d, tmin, tmax);
+      w.begin(S, o, d, tmin, tmax);
+      while (w.cur != CHILD_EMPTY) {
+#pragma unroll
+        for (int k = 0; k < PTAMD_NODE_STEPS; k++)
+          if (w.cur >= 0) w.template node_step<COUNT>(S, stack, n_nodes);
+        if (w.cur < 0 && w.cur != CHILD_EMPTY && w.template prim_step<ANY, COUNT>(S, stack, n_tests)) break;
+      }
+      pol.store(i, w.hit, w.hit.prim >= 0);
+    }
+    return;
+  }
+  constexpr uint32_t GRAB = PTAMD_GRAB;
+  const int lane = threadIdx.x & 63;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  uint32_t next = 0, end = 0, idx = 0;
+  bool exhausted = false, active = false;
+  w.cur = CHILD_EMPTY;
+  w.sp = 0;
+  for (;;) {
+    const unsigned long long idle = __ballot(!active);
+    const int n_idle = __popcll(idle);
+    if (n_idle >= REFILL && !exhausted) {
+      if (next >= end) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(grab, GRAB);
+        base = (uint32_t)__shfl((int)base, 0);
+        next = base;
+        end = base + GRAB < n ? base + GRAB : n;
+        if (base >= n) { exhausted = true; next = end = 0; }
+      }
+      if (next < end) {
+        // idle lanes take the next rays in lane order
+        const uint32_t mine = next + (uint32_t)__popcll(idle & below);
+        if (!active && mine < end) {
+          idx = mine;
+          v3 o, d;
+          double tmin, tmax;
+          pol.load(idx, o, d, tmin, tmax);
+          w.begin(S, o, d, tmin, tmax);
+          active = true;
+        }
+        next = next + (uint32_t)n_idle < end ? next + (uint32_t)n_idle : end;
+      }
+    }
+    if (!__ballot(active)) {
+      if (exhausted) break;  // every wave gets here: the list is finite and claimed monotonically
+      continue;
+    }
+    if (active) {
 #pragma unroll
       for (int k = 0; k < PTAMD_NODE_STEPS; k++)
         if (w.cur >= 0) w.template node_step<COUNT>(S, stack, n_nodes);
-      if (w.cur < 0 && w.cur != CHILD_EMPTY && w.template prim_step<ANY, COUNT>(S, stack, n_tests)) break;
+      bool done = w.cur == CHILD_EMPTY;
+      if (!done && w.cur < 0) done = w.template prim_step<ANY, COUNT>(S, stack, n_tests) || w.cur == CHILD_EMPTY;
+      if (done) {
+        pol.store(idx, w.hit, w.hit.prim >= 0);
+        active = false;
+      }
     }
-    pol.store(i, w.hit, w.hit.prim >= 0);
   }
 }
 
@@ -560,6 +630,7 @@ __global__ void k_set_counts(Ctl *ctl, PixView pv, uint32_t p0, uint32_t chunk, 
   ctl->n_cur = np * ns;
   ctl->n_next = 0;
   ctl->n_shadow = 0;
+  ctl->grab[0] = ctl->grab[1] = 0;
 }
 
 // end of one depth: fold the stage's counts into the statistics, make the next
@@ -570,6 +641,7 @@ __global__ void k_advance(Ctl *ctl) {
   ctl->n_cur = ctl->n_next;
   ctl->n_next = 0;
   ctl->n_shadow = 0;
+  ctl->grab[0] = ctl->grab[1] = 0;
 }
 
 // Camera::generate_ray, src/pathtracer/camera.cpp:190-203
@@ -647,14 +719,14 @@ struct ExtendPolicy {
 };
 
 template <bool COUNT>
-__global__ void TRAV_BOUNDS
+__global__ void TRAV_BOUNDS_N(PTAMD_WAVES_EXTEND)
     k_extend(DevScene S, RayQ q, const int32_t *__restrict__ list, HitBuf hb, Ctl *ctl, double min_t, double max_t,
              uint2 *gstack) {
   extern __shared__ uint2 lds_stack[];
   const TravStack stack{lds_stack, gstack, gridDim.x * blockDim.x, blockIdx.x * blockDim.x + threadIdx.x};
   uint32_t cn = 0, ct = 0;
   const ExtendPolicy pol{q, list, hb, min_t, max_t};
-  trace_rays<false, COUNT>(S, pol, ctl->n_cur, stack, cn, ct);
+  trace_rays<false, COUNT, PTAMD_REFILL_EXTEND>(S, pol, ctl->n_cur, &ctl->grab[0], stack, cn, ct);
   if (COUNT) {
     atomicAdd(&ctl->st_nodes, (unsigned long long)cn);
     atomicAdd(&ctl->st_tests, (unsigned long long)ct);
@@ -700,14 +772,14 @@ struct ShadowPolicy {
 };
 
 template <bool HEMI, bool COUNT>
-__global__ void TRAV_BOUNDS
+__global__ void TRAV_BOUNDS_N(PTAMD_WAVES_SHADOW)
     k_shadow(DevScene S, ShadowQ sq, VertexBuf vb, Ctl *ctl, int32_t nls, uint2 *gstack) {
   extern __shared__ uint2 lds_stack[];
   const TravStack stack{lds_stack, gstack, gridDim.x * blockDim.x, blockIdx.x * blockDim.x + threadIdx.x};
   uint32_t cn = 0, ct = 0;
   const ShadowPolicy<HEMI> pol{S, sq, vb, (uint32_t)nls};
-  if (HEMI) trace_rays<false, COUNT>(S, pol, ctl->n_shadow, stack, cn, ct);
-  else trace_rays<true, COUNT>(S, pol, ctl->n_shadow, stack, cn, ct);
+  if (HEMI) trace_rays<false, COUNT, PTAMD_REFILL_SHADOW>(S, pol, ctl->n_shadow, &ctl->grab[1], stack, cn, ct);
+  else trace_rays<true, COUNT, PTAMD_REFILL_SHADOW>(S, pol, ctl->n_shadow, &ctl->grab[1], stack, cn, ct);
   if (COUNT) {
     atomicAdd(&ctl->st_nodes, (unsigned long long)cn);
     atomicAdd(&ctl->st_tests, (unsigned long long)ct);
@@ -1812,7 +1884,8 @@ int ptamd_frame_begin(ptamd_context *c, const ptamd_render_params *p) {
 // Launch shape of the traversal kernels: 256-thread workgroups, STACK_LDS stack
 // levels per lane in LDS, the rest (if the tree is deeper) in a global strip.
 struct TravLaunch {
-  int block, grid;
+  int block;
+  int grid_extend, grid_shadow;  // grid-stride driver: a few workgroups per resident slot; persistent: exactly the resident ones
   size_t lds;
   uint2 *gstack;
 };
@@ -1820,14 +1893,11 @@ static int traversal_launch(ptamd_context *c, TravLaunch *t) {
   t->block = TRAV_BLOCK;
   t->lds = (size_t)t->block * (STACK_LDS + 1) * sizeof(uint2);  // + the scratch level
   // resident workgroups per CU: bounded by LDS (160 KiB per CU) and by registers
-  // (about 5 waves per SIMD). The waves are persistent, so the grid is exactly
-  // the resident set
-  const int reg_waves = PTAMD_WAVES_PER_EU > 0 ? PTAMD_WAVES_PER_EU : 5;
-  const int wg_per_cu = std::max(1, std::min<int>((int)((160 * 1024) / std::max<size_t>(t->lds, 1)), reg_waves));
-  // a few workgroups per resident slot, so a CU always has one to start when one drains
-  t->grid = c->num_cu * wg_per_cu * PTAMD_GRID_MULT;
+  const int by_lds = (int)((160 * 1024) / std::max<size_t>(t->lds, 1));
+  t->grid_extend = c->num_cu * std::max(1, std::min(by_lds, PTAMD_WAVES_EXTEND)) * (PTAMD_REFILL_EXTEND ? 1 : PTAMD_GRID_MULT);
+  t->grid_shadow = c->num_cu * std::max(1, std::min(by_lds, PTAMD_WAVES_SHADOW)) * (PTAMD_REFILL_SHADOW ? 1 : PTAMD_GRID_MULT);
   const size_t levels = (size_t)std::max(0, c->S.stack_cap - STACK_LDS);
-  const size_t need = levels * (size_t)t->grid * t->block * sizeof(uint2);
+  const size_t need = levels * (size_t)std::max(t->grid_extend, t->grid_shadow) * t->block * sizeof(uint2);
   if (need > c->gstack_bytes) {
     if (c->gstack) { HIPCHK(hipDeviceSynchronize()); HIPCHK(hipFree(c->gstack)); c->gstack = nullptr; }
     HIPCHK(hipMalloc((void **)&c->gstack, need));
@@ -1880,7 +1950,8 @@ int ptamd_trace_list(ptamd_context *c, const ptamd_pixel_list *list, int32_t sam
   TravLaunch tl;
   rc = traversal_launch(c, &tl);
   if (rc) return rc;
-  const int tblock = tl.block, tgrid = tl.grid;
+  const int tblock = tl.block;
+  const int egrid = tl.grid_extend, sgrid = tl.grid_shadow;
   const size_t lds = tl.lds;
   uint2 *gstack = tl.gstack;
   const int ggrid = grid_for(c, 8);
@@ -1901,8 +1972,8 @@ int ptamd_trace_list(ptamd_context *c, const ptamd_pixel_list *list, int32_t sam
       const double max_t = depth == 1 ? fp.f_clip : (double)INFINITY;
       const int32_t *lst = depth == 1 ? nullptr : c->list[cur];
       L.begin(PTAMD_K_EXTEND);
-      if (c->prof_counters) hipLaunchKernelGGL((k_extend<true>), tgrid, tblock, lds, s, c->S, c->q[cur], lst, c->hb, c->ctl, min_t, max_t, gstack);
-      else hipLaunchKernelGGL((k_extend<false>), tgrid, tblock, lds, s, c->S, c->q[cur], lst, c->hb, c->ctl, min_t, max_t, gstack);
+      if (c->prof_counters) hipLaunchKernelGGL((k_extend<true>), egrid, tblock, lds, s, c->S, c->q[cur], lst, c->hb, c->ctl, min_t, max_t, gstack);
+      else hipLaunchKernelGGL((k_extend<false>), egrid, tblock, lds, s, c->S, c->q[cur], lst, c->hb, c->ctl, min_t, max_t, gstack);
       L.end();
       L.begin(PTAMD_K_SHADE);
       if (fp.hemisphere)
@@ -1919,11 +1990,11 @@ int ptamd_trace_list(ptamd_context *c, const ptamd_pixel_list *list, int32_t sam
       if (fp.max_ray_depth > 0 && fp.nls > 0) {
         L.begin(PTAMD_K_SHADOW);
         if (fp.hemisphere) {
-          if (c->prof_counters) hipLaunchKernelGGL((k_shadow<true, true>), tgrid, tblock, lds, s, c->S, c->sq, c->vb, c->ctl, nls, gstack);
-          else hipLaunchKernelGGL((k_shadow<true, false>), tgrid, tblock, lds, s, c->S, c->sq, c->vb, c->ctl, nls, gstack);
+          if (c->prof_counters) hipLaunchKernelGGL((k_shadow<true, true>), sgrid, tblock, lds, s, c->S, c->sq, c->vb, c->ctl, nls, gstack);
+          else hipLaunchKernelGGL((k_shadow<true, false>), sgrid, tblock, lds, s, c->S, c->sq, c->vb, c->ctl, nls, gstack);
         } else {
-          if (c->prof_counters) hipLaunchKernelGGL((k_shadow<false, true>), tgrid, tblock, lds, s, c->S, c->sq, c->vb, c->ctl, nls, gstack);
-          else hipLaunchKernelGGL((k_shadow<false, false>), tgrid, tblock, lds, s, c->S, c->sq, c->vb, c->ctl, nls, gstack);
+          if (c->prof_counters) hipLaunchKernelGGL((k_shadow<false, true>), sgrid, tblock, lds, s, c->S, c->sq, c->vb, c->ctl, nls, gstack);
+          else hipLaunchKernelGGL((k_shadow<false, false>), sgrid, tblock, lds, s, c->S, c->sq, c->vb, c->ctl, nls, gstack);
         }
         L.end();
         L.begin(PTAMD_K_RESOLVE);
@@ -2158,7 +2229,7 @@ int ptamd_trace_primary(ptamd_context *c, int64_t n, const double *sx, const dou
   TravLaunch tl;
   rc = traversal_launch(c, &tl);
   if (rc) return rc;
-  const int tblock = tl.block, tgrid = tl.grid;
+  const int tblock = tl.block, tgrid = tl.grid_extend;
   const size_t lds = tl.lds;
   hipStream_t s = c->own_stream;
   // the queue's throughput arrays are unused here and double as staging for sx, sy

@@ -141,7 +141,7 @@ struct ShadowQ {
   SRay *ray;      // [cap * nls]
 };
 struct VertexBuf {
-  double *hp[3];     // hit point per queue entry (shadow-ray origin)
+  double *hp[3];     // hit point per queue entry (shadow-ray origin): the origin arrays of the next ray queue
   uint8_t *flag;     // bit 0: has light samples, bit 1: result goes to `pending`
   Contrib *contrib;  // [cap * nls]
   uint8_t *vis;      // [cap * nls]
@@ -452,11 +452,11 @@ struct Walk {
 //  REFILL > 0: persistent waves. A wave claims rays in chunks of GRAB from a
 //    counter shared by the launch, and once REFILL of its lanes are idle they are
 //    given the next rays. Which lane traces a ray does not affect where its
-//    result is stored. Lanes that start together share the top of the tree (one
-//    cache line serves the wave) while refilled lanes are all over it, and the
-//    bookkeeping costs registers: measured on MI355X this wins for shadow rays
-//    (coherent: they converge on the light; -18 % on CBbunny) and loses for
-//    bounce rays (+5 to +15 %), so each kernel picks its driver.
+//    result is stored. Measured on MI355X: -18 % for shadow rays and -19 % for
+//    bounce rays PROVIDED the kernel does not spill: the bookkeeping costs about
+//    ten registers, and with spills in the loop the same driver was 30 to 90 %
+//    slower than the grid-stride one. Hence closest-hit walks run at 5 waves per
+//    SIMD (no spills) and any-hit walks, which carry less state, at 6.
 //
 // Also measured and rejected: sorting each workgroup's 256 rays by direction
 // octant (no gain); one box step or one primitive test per trip (if / else),
@@ -675,7 +675,6 @@ __global__ void k_generate(FrameParams fp, DevScene S, PixView pv, uint32_t p0, 
     q.path[k] = (int32_t)k;
     q.o[0][k] = o.x; q.o[1][k] = o.y; q.o[2][k] = o.z;
     q.d[0][k] = d.x; q.d[1][k] = d.y; q.d[2][k] = d.z;
-    q.T[0][k] = 1.0; q.T[1][k] = 1.0; q.T[2][k] = 1.0;
     pb.rad[0][k] = 0; pb.rad[1][k] = 0; pb.rad[2][k] = 0;
     if (pb.pend[0]) { pb.pend[0][k] = 0; pb.pend[1][k] = 0; pb.pend[2][k] = 0; }
   }
@@ -983,7 +982,8 @@ __global__ void __launch_bounds__(256)
           }
         }
         vb.flag[i] = flag;
-        if (flag) { vb.hp[0][i] = hit_p.x; vb.hp[1][i] = hit_p.y; vb.hp[2][i] = hit_p.z; }
+        // the hit point: origin of the vertex's shadow rays and of its bounce ray (vb.hp IS qn.o)
+        if (flag || push) { vb.hp[0][i] = hit_p.x; vb.hp[1][i] = hit_p.y; vb.hp[2][i] = hit_p.z; }
       }
       cp.pflag[i] = push ? 1 : 0;
     }
@@ -991,7 +991,6 @@ __global__ void __launch_bounds__(256)
     // for the light-sample loop)
     if (push) {
       qn.path[i] = path | via;
-      qn.o[0][i] = hit_p.x; qn.o[1][i] = hit_p.y; qn.o[2][i] = hit_p.z;
       qn.d[0][i] = next_d.x; qn.d[1][i] = next_d.y; qn.d[2][i] = next_d.z;
       qn.T[0][i] = next_T.x; qn.T[1][i] = next_T.y; qn.T[2][i] = next_T.z;
     }
@@ -1470,7 +1469,6 @@ int ensure_buffers(ptamd_context *c, int64_t paths, int nls, bool pend) {
   for (int j = 1; j < 4; j++) off_hit[j] = take(P * 8);
   off_sq[0] = take(PN * 4);
   off_sq[1] = take(PN * sizeof(SRay));
-  for (int j = 0; j < 3; j++) off_vb[j] = take(P * 8);
   off_vb[3] = take(P);
   off_vb[4] = take(PN * sizeof(Contrib));
   off_vb[7] = take(PN + 4);
@@ -1496,7 +1494,7 @@ int ensure_buffers(ptamd_context *c, int64_t paths, int nls, bool pend) {
   c->hb.v = (double *)(b + off_hit[3]);
   c->sq.slot = (int32_t *)(b + off_sq[0]);
   c->sq.ray = (SRay *)(b + off_sq[1]);
-  for (int j = 0; j < 3; j++) c->vb.hp[j] = (double *)(b + off_vb[j]);
+  for (int j = 0; j < 3; j++) c->vb.hp[j] = nullptr;  // set per depth: the next ray queue's origin arrays
   c->vb.flag = (uint8_t *)(b + off_vb[3]);
   c->vb.contrib = (Contrib *)(b + off_vb[4]);
   c->vb.vis = (uint8_t *)(b + off_vb[7]);
@@ -1975,30 +1973,32 @@ int ptamd_trace_list(ptamd_context *c, const ptamd_pixel_list *list, int32_t sam
       if (c->prof_counters) hipLaunchKernelGGL((k_extend<true>), egrid, tblock, lds, s, c->S, c->q[cur], lst, c->hb, c->ctl, min_t, max_t, gstack);
       else hipLaunchKernelGGL((k_extend<false>), egrid, tblock, lds, s, c->S, c->q[cur], lst, c->hb, c->ctl, min_t, max_t, gstack);
       L.end();
+      VertexBuf vb = c->vb;
+      for (int k = 0; k < 3; k++) vb.hp[k] = c->q[cur ^ 1].o[k];  // one copy of the hit point serves both uses
       L.begin(PTAMD_K_SHADE);
       if (fp.hemisphere)
-        hipLaunchKernelGGL(k_shade<true>, ggrid, 256, 0, s, fp, c->S, c->q[cur], lst, c->hb, c->q[cur ^ 1], c->sq, c->vb, pb,
+        hipLaunchKernelGGL(k_shade<true>, ggrid, 256, 0, s, fp, c->S, c->q[cur], lst, c->hb, c->q[cur ^ 1], c->sq, vb, pb,
                            c->cp, c->ctl, depth, pv, up0, sample_base, n_samples);
       else
-        hipLaunchKernelGGL(k_shade<false>, ggrid, 256, 0, s, fp, c->S, c->q[cur], lst, c->hb, c->q[cur ^ 1], c->sq, c->vb, pb,
+        hipLaunchKernelGGL(k_shade<false>, ggrid, 256, 0, s, fp, c->S, c->q[cur], lst, c->hb, c->q[cur ^ 1], c->sq, vb, pb,
                            c->cp, c->ctl, depth, pv, up0, sample_base, n_samples);
       L.end();
       L.begin(PTAMD_K_OTHER);
       hipLaunchKernelGGL(k_scan2, 1, 1024, 0, s, c->cp, c->ctl);
-      hipLaunchKernelGGL(k_scatter, ggrid, 256, 0, s, c->cp, c->vb, c->list[cur ^ 1], c->sq, c->ctl, fp.max_ray_depth > 0 ? fp.nls : 0);
+      hipLaunchKernelGGL(k_scatter, ggrid, 256, 0, s, c->cp, vb, c->list[cur ^ 1], c->sq, c->ctl, fp.max_ray_depth > 0 ? fp.nls : 0);
       L.end();
       if (fp.max_ray_depth > 0 && fp.nls > 0) {
         L.begin(PTAMD_K_SHADOW);
         if (fp.hemisphere) {
-          if (c->prof_counters) hipLaunchKernelGGL((k_shadow<true, true>), sgrid, tblock, lds, s, c->S, c->sq, c->vb, c->ctl, nls, gstack);
-          else hipLaunchKernelGGL((k_shadow<true, false>), sgrid, tblock, lds, s, c->S, c->sq, c->vb, c->ctl, nls, gstack);
+          if (c->prof_counters) hipLaunchKernelGGL((k_shadow<true, true>), sgrid, tblock, lds, s, c->S, c->sq, vb, c->ctl, nls, gstack);
+          else hipLaunchKernelGGL((k_shadow<true, false>), sgrid, tblock, lds, s, c->S, c->sq, vb, c->ctl, nls, gstack);
         } else {
-          if (c->prof_counters) hipLaunchKernelGGL((k_shadow<false, true>), sgrid, tblock, lds, s, c->S, c->sq, c->vb, c->ctl, nls, gstack);
-          else hipLaunchKernelGGL((k_shadow<false, false>), sgrid, tblock, lds, s, c->S, c->sq, c->vb, c->ctl, nls, gstack);
+          if (c->prof_counters) hipLaunchKernelGGL((k_shadow<false, true>), sgrid, tblock, lds, s, c->S, c->sq, vb, c->ctl, nls, gstack);
+          else hipLaunchKernelGGL((k_shadow<false, false>), sgrid, tblock, lds, s, c->S, c->sq, vb, c->ctl, nls, gstack);
         }
         L.end();
         L.begin(PTAMD_K_RESOLVE);
-        hipLaunchKernelGGL(k_resolve, ggrid, 256, 0, s, fp, c->q[cur], lst, c->vb, pb, c->ctl, depth);
+        hipLaunchKernelGGL(k_resolve, ggrid, 256, 0, s, fp, c->q[cur], lst, vb, pb, c->ctl, depth);
         hipLaunchKernelGGL(k_advance, 1, 1, 0, s, c->ctl);
         L.end();
       } else {

@@ -207,10 +207,13 @@ __device__ __forceinline__ RayF make_rayf(v3 o, v3 d, double min_t) {
 // deeper levels spill to a per-thread strip of global memory. LDS level
 // STACK_LDS is a scratch slot: a push that turns out not to be needed is
 // redirected there instead of being branched around.
-#ifndef PTAMD_STACK_LDS
-#define PTAMD_STACK_LDS 10
+// (levels: a TravStack member, chosen per kernel from the LDS its occupancy leaves)
+#ifndef PTAMD_STACK_EXTEND
+#define PTAMD_STACK_EXTEND 14  // 5 workgroups per CU x 30 KiB
 #endif
-constexpr int STACK_LDS = PTAMD_STACK_LDS;
+#ifndef PTAMD_STACK_SHADOW
+#define PTAMD_STACK_SHADOW 12  // 6 workgroups per CU x 26 KiB
+#endif
 // Build-time tuning of the traversal kernels (defaults are the measured best):
 // resident waves per SIMD the register allocator must make room for (0: its own
 // choice; 6 costs a few spilled registers and still wins, 7 loses, 8 does not
@@ -243,6 +246,7 @@ struct TravStack {
   uint2 *lds;
   uint2 *glob;
   uint32_t gstride, gtid;
+  int STACK_LDS;  // levels held in LDS
   __device__ __forceinline__ void put(int level, uint2 e) const {
     if (level < STACK_LDS) lds[level * TRAV_BLOCK + threadIdx.x] = e;
     else glob[(size_t)(level - STACK_LDS) * gstride + gtid] = e;
@@ -300,7 +304,7 @@ struct Walk {
   // pop, skipping subtrees that begin beyond the current hit
   __device__ __forceinline__ void pop(const TravStack &stack) {
     cur = CHILD_EMPTY;
-    if (sp <= STACK_LDS) {
+    if (sp <= stack.STACK_LDS) {
       while (sp > 0) {
         sp--;
         const uint2 e = stack.get_lds(sp);
@@ -369,10 +373,10 @@ struct Walk {
       // the accepted children are a prefix of the sorted four; the farthest goes
       // deepest. nv = accepted among 1..3; c[k] lands on level sp + nv - k.
       const int nv = (t[1] < FINF) + (t[2] < FINF) + (t[3] < FINF);
-      if (sp + 3 <= STACK_LDS) {
+      if (sp + 3 <= stack.STACK_LDS) {
 #pragma unroll
         for (int k = 1; k < 4; k++)
-          stack.put_lds(k <= nv ? sp + nv - k : STACK_LDS, make_uint2((uint32_t)c[k], __float_as_uint(t[k])));
+          stack.put_lds(k <= nv ? sp + nv - k : stack.STACK_LDS, make_uint2((uint32_t)c[k], __float_as_uint(t[k])));
       } else {
 #pragma unroll
         for (int k = 1; k < 4; k++)
@@ -722,7 +726,7 @@ __global__ void TRAV_BOUNDS_N(PTAMD_WAVES_EXTEND)
     k_extend(DevScene S, RayQ q, const int32_t *__restrict__ list, HitBuf hb, Ctl *ctl, double min_t, double max_t,
              uint2 *gstack) {
   extern __shared__ uint2 lds_stack[];
-  const TravStack stack{lds_stack, gstack, gridDim.x * blockDim.x, blockIdx.x * blockDim.x + threadIdx.x};
+  const TravStack stack{lds_stack, gstack, gridDim.x * blockDim.x, blockIdx.x * blockDim.x + threadIdx.x, PTAMD_STACK_EXTEND};
   uint32_t cn = 0, ct = 0;
   const ExtendPolicy pol{q, list, hb, min_t, max_t};
   trace_rays<false, COUNT, PTAMD_REFILL_EXTEND>(S, pol, ctl->n_cur, &ctl->grab[0], stack, cn, ct);
@@ -774,7 +778,7 @@ template <bool HEMI, bool COUNT>
 __global__ void TRAV_BOUNDS_N(PTAMD_WAVES_SHADOW)
     k_shadow(DevScene S, ShadowQ sq, VertexBuf vb, Ctl *ctl, int32_t nls, uint2 *gstack) {
   extern __shared__ uint2 lds_stack[];
-  const TravStack stack{lds_stack, gstack, gridDim.x * blockDim.x, blockIdx.x * blockDim.x + threadIdx.x};
+  const TravStack stack{lds_stack, gstack, gridDim.x * blockDim.x, blockIdx.x * blockDim.x + threadIdx.x, PTAMD_STACK_SHADOW};
   uint32_t cn = 0, ct = 0;
   const ShadowPolicy<HEMI> pol{S, sq, vb, (uint32_t)nls};
   if (HEMI) trace_rays<false, COUNT, PTAMD_REFILL_SHADOW>(S, pol, ctl->n_shadow, &ctl->grab[1], stack, cn, ct);
@@ -1879,22 +1883,23 @@ int ptamd_frame_begin(ptamd_context *c, const ptamd_render_params *p) {
   return PTAMD_OK;
 }
 
-// Launch shape of the traversal kernels: 256-thread workgroups, STACK_LDS stack
+// Launch shape of the traversal kernels: 256-thread workgroups, PTAMD_STACK_* stack
 // levels per lane in LDS, the rest (if the tree is deeper) in a global strip.
 struct TravLaunch {
   int block;
+  size_t lds_extend, lds_shadow;
   int grid_extend, grid_shadow;  // grid-stride driver: a few workgroups per resident slot; persistent: exactly the resident ones
-  size_t lds;
   uint2 *gstack;
 };
 static int traversal_launch(ptamd_context *c, TravLaunch *t) {
   t->block = TRAV_BLOCK;
-  t->lds = (size_t)t->block * (STACK_LDS + 1) * sizeof(uint2);  // + the scratch level
+  t->lds_extend = (size_t)t->block * (PTAMD_STACK_EXTEND + 1) * sizeof(uint2);  // + the scratch level
+  t->lds_shadow = (size_t)t->block * (PTAMD_STACK_SHADOW + 1) * sizeof(uint2);
   // resident workgroups per CU: bounded by LDS (160 KiB per CU) and by registers
-  const int by_lds = (int)((160 * 1024) / std::max<size_t>(t->lds, 1));
-  t->grid_extend = c->num_cu * std::max(1, std::min(by_lds, PTAMD_WAVES_EXTEND)) * (PTAMD_REFILL_EXTEND ? 1 : PTAMD_GRID_MULT);
-  t->grid_shadow = c->num_cu * std::max(1, std::min(by_lds, PTAMD_WAVES_SHADOW)) * (PTAMD_REFILL_SHADOW ? 1 : PTAMD_GRID_MULT);
-  const size_t levels = (size_t)std::max(0, c->S.stack_cap - STACK_LDS);
+  const int lds_e = (int)((160 * 1024) / t->lds_extend), lds_s = (int)((160 * 1024) / t->lds_shadow);
+  t->grid_extend = c->num_cu * std::max(1, std::min(lds_e, PTAMD_WAVES_EXTEND)) * (PTAMD_REFILL_EXTEND ? 1 : PTAMD_GRID_MULT);
+  t->grid_shadow = c->num_cu * std::max(1, std::min(lds_s, PTAMD_WAVES_SHADOW)) * (PTAMD_REFILL_SHADOW ? 1 : PTAMD_GRID_MULT);
+  const size_t levels = (size_t)std::max(0, c->S.stack_cap - std::min(PTAMD_STACK_EXTEND, PTAMD_STACK_SHADOW));
   const size_t need = levels * (size_t)std::max(t->grid_extend, t->grid_shadow) * t->block * sizeof(uint2);
   if (need > c->gstack_bytes) {
     if (c->gstack) { HIPCHK(hipDeviceSynchronize()); HIPCHK(hipFree(c->gstack)); c->gstack = nullptr; }
@@ -1950,7 +1955,7 @@ int ptamd_trace_list(ptamd_context *c, const ptamd_pixel_list *list, int32_t sam
   if (rc) return rc;
   const int tblock = tl.block;
   const int egrid = tl.grid_extend, sgrid = tl.grid_shadow;
-  const size_t lds = tl.lds;
+  const size_t elds = tl.lds_extend, slds = tl.lds_shadow;
   uint2 *gstack = tl.gstack;
   const int ggrid = grid_for(c, 8);
   PathBuf pb = c->pb;
@@ -1970,8 +1975,8 @@ int ptamd_trace_list(ptamd_context *c, const ptamd_pixel_list *list, int32_t sam
       const double max_t = depth == 1 ? fp.f_clip : (double)INFINITY;
       const int32_t *lst = depth == 1 ? nullptr : c->list[cur];
       L.begin(PTAMD_K_EXTEND);
-      if (c->prof_counters) hipLaunchKernelGGL((k_extend<true>), egrid, tblock, lds, s, c->S, c->q[cur], lst, c->hb, c->ctl, min_t, max_t, gstack);
-      else hipLaunchKernelGGL((k_extend<false>), egrid, tblock, lds, s, c->S, c->q[cur], lst, c->hb, c->ctl, min_t, max_t, gstack);
+      if (c->prof_counters) hipLaunchKernelGGL((k_extend<true>), egrid, tblock, elds, s, c->S, c->q[cur], lst, c->hb, c->ctl, min_t, max_t, gstack);
+      else hipLaunchKernelGGL((k_extend<false>), egrid, tblock, elds, s, c->S, c->q[cur], lst, c->hb, c->ctl, min_t, max_t, gstack);
       L.end();
       VertexBuf vb = c->vb;
       for (int k = 0; k < 3; k++) vb.hp[k] = c->q[cur ^ 1].o[k];  // one copy of the hit point serves both uses
@@ -1990,11 +1995,11 @@ int ptamd_trace_list(ptamd_context *c, const ptamd_pixel_list *list, int32_t sam
       if (fp.max_ray_depth > 0 && fp.nls > 0) {
         L.begin(PTAMD_K_SHADOW);
         if (fp.hemisphere) {
-          if (c->prof_counters) hipLaunchKernelGGL((k_shadow<true, true>), sgrid, tblock, lds, s, c->S, c->sq, vb, c->ctl, nls, gstack);
-          else hipLaunchKernelGGL((k_shadow<true, false>), sgrid, tblock, lds, s, c->S, c->sq, vb, c->ctl, nls, gstack);
+          if (c->prof_counters) hipLaunchKernelGGL((k_shadow<true, true>), sgrid, tblock, slds, s, c->S, c->sq, vb, c->ctl, nls, gstack);
+          else hipLaunchKernelGGL((k_shadow<true, false>), sgrid, tblock, slds, s, c->S, c->sq, vb, c->ctl, nls, gstack);
         } else {
-          if (c->prof_counters) hipLaunchKernelGGL((k_shadow<false, true>), sgrid, tblock, lds, s, c->S, c->sq, vb, c->ctl, nls, gstack);
-          else hipLaunchKernelGGL((k_shadow<false, false>), sgrid, tblock, lds, s, c->S, c->sq, vb, c->ctl, nls, gstack);
+          if (c->prof_counters) hipLaunchKernelGGL((k_shadow<false, true>), sgrid, tblock, slds, s, c->S, c->sq, vb, c->ctl, nls, gstack);
+          else hipLaunchKernelGGL((k_shadow<false, false>), sgrid, tblock, slds, s, c->S, c->sq, vb, c->ctl, nls, gstack);
         }
         L.end();
         L.begin(PTAMD_K_RESOLVE);
@@ -2230,7 +2235,7 @@ int ptamd_trace_primary(ptamd_context *c, int64_t n, const double *sx, const dou
   rc = traversal_launch(c, &tl);
   if (rc) return rc;
   const int tblock = tl.block, tgrid = tl.grid_extend;
-  const size_t lds = tl.lds;
+  const size_t lds = tl.lds_extend;
   hipStream_t s = c->own_stream;
   // the queue's throughput arrays are unused here and double as staging for sx, sy
   double *d_sx = c->q[0].T[0], *d_sy = c->q[0].T[1];

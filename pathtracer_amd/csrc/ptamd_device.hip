@@ -492,7 +492,9 @@ __device__ __forceinline__ void trace_rays(const DevScene &S, const Policy &pol,
     }
     return;
   }
-  constexpr uint32_t GRAB = PTAMD_GRAB;
+  // rays claimed at a time: PTAMD_GRAB, less when the list is too short to give every wave that many
+  const uint32_t per_wave = n / (gridDim.x * (TRAV_BLOCK / 64u));
+  const uint32_t GRAB = per_wave >= PTAMD_GRAB ? PTAMD_GRAB : (per_wave < 64u ? 64u : (per_wave & ~63u));
   const int lane = threadIdx.x & 63;
   const unsigned long long below = (1ull << lane) - 1ull;
   uint32_t next = 0, end = 0, idx = 0;

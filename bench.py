@@ -53,6 +53,8 @@ def parse_args():
     ap.add_argument("--cpu-spp", type=int, default=256)
     ap.add_argument("--target-paths", type=int, default=16 << 20, help="see PixelSchedule.batches")
     ap.add_argument("--max-batches", type=int, default=32)
+    ap.add_argument("--per-pixel", type=int, default=0,
+                    help="1: pixels are traced ahead only as far as their statistics predict (see render_frame)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL; the real thing) or gloo (rehearsal of the "
                     "multi-rank flow with several ranks on one GPU, rows staged through the host)")
     ap.add_argument("--pixel-stride", type=int, default=1,
@@ -187,7 +189,7 @@ def main():
                              ns_area_light=args.light_samples, seed=seed, specular=args.specular)
         hdr, cnt = distributed.render_frame(dev, p, rank=rank, world=world, device=device,
                                             pixel_stride=args.pixel_stride, target_paths=args.target_paths,
-                                            max_batches=args.max_batches)
+                                            max_batches=args.max_batches, per_pixel=bool(args.per_pixel))
         return cnt
 
     for i in range(args.warmup):

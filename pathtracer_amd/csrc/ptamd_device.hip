@@ -96,7 +96,7 @@ struct FrameParams {
 struct Ctl {
   uint32_t n_cur, n_next, n_shadow, n_pix;  // sizes of the ray lists; pixels of the running chunk
   uint32_t grab[4];  // next unclaimed ray of the running extend / shadow kernel (persistent driver)
-  unsigned long long st_rays, st_shadow, st_vertices, st_nodes, st_tests, st_samples;
+  unsigned long long st_rays, st_shadow, st_vertices, st_nodes, st_tests, st_samples, st_dead;
 };
 
 // A shard of a device-resident pixel list: entries offset, offset + stride, ...
@@ -149,6 +149,47 @@ struct VertexBuf {
 struct PathBuf {
   double *rad[3];
   double *pend[3];
+};
+
+// What a round traces for one pixel. With sample_base >= 0 the caller drives the
+// cadence: samples [sample_base, sample_base + ns) for every listed pixel. With
+// sample_base < 0 every pixel continues from its own count (state[5]) and gets
+// as many batches, up to ns / batch, as its statistics say it will still need:
+// the adaptive test passes once 1.96 sqrt(var / n) <= tol mean, i.e. from
+// n = (1.96 / tol)^2 var / mean^2 on. A pixel predicted to stop soon is not
+// traced far ahead of its tests; a wrong guess only costs it another round. The
+// prediction never changes which samples a pixel ends up with (samples are
+// keyed by their index, tests run at every multiple of `batch`), only when they
+// are traced.
+struct RoundPlan {
+  const double *state;
+  double tol;
+  int32_t sample_base, ns, batch, ns_aa;
+  int32_t predict;  // 0: every pixel gets all ns samples (a launch too small for dropped samples to matter)
+  __device__ __forceinline__ int32_t first_of(const double *st) const {
+    return sample_base >= 0 ? sample_base : (int32_t)st[5];
+  }
+  // number of samples to trace for the pixel with state row st; first = index of the first
+  __device__ __forceinline__ int32_t planned(const double *st, int32_t &first) const {
+    if (sample_base >= 0) { first = sample_base; return ns; }
+    const int32_t n = (int32_t)st[5];
+    first = n;
+    int32_t want = ns;
+    if (predict && n >= 2) {
+      const double s1 = st[0], s2 = st[1];
+      const double mean = s1 / n, var = (s2 - s1 * s1 / n) / (n - 1);
+      const double c = 1.96 / tol;
+      // 1.5: erring on the long side costs a few dropped samples, erring on the short side a round
+      const double need = 1.5 * (c * c * var / (mean * mean) - n);
+      if (need == need) {  // not NaN
+        double kb = ceil(need / batch);
+        kb = kb < 1 ? 1 : (kb > (double)(ns / batch) ? (double)(ns / batch) : kb);
+        want = (int32_t)kb * batch;
+      }
+    }
+    const int32_t left = ns_aa - n;
+    return want < left ? want : (left > 0 ? left : 0);
+  }
 };
 
 // ------------------------------------------------------------------ intersection
@@ -480,7 +521,7 @@ __device__ __forceinline__ void trace_rays(const DevScene &S, const Policy &pol,
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
       v3 o, d;
       double tmin, tmax;
-      pol.load(i, o, d, tmin, tmax);
+      if (!pol.load(i, o, d, tmin, tmax)) continue;
       w.begin(S, o, d, tmin, tmax);
       while (w.cur != CHILD_EMPTY) {
 #pragma unroll
@@ -520,9 +561,10 @@ __device__ __forceinline__ void trace_rays(const DevScene &S, const Policy &pol,
           idx = mine;
           v3 o, d;
           double tmin, tmax;
-          pol.load(idx, o, d, tmin, tmax);
-          w.begin(S, o, d, tmin, tmax);
-          active = true;
+          if (pol.load(idx, o, d, tmin, tmax)) {
+            w.begin(S, o, d, tmin, tmax);
+            active = true;
+          }
         }
         next = next + (uint32_t)n_idle < end ? next + (uint32_t)n_idle : end;
       }
@@ -661,13 +703,26 @@ __device__ __forceinline__ void camera_ray(const FrameParams &fp, double x, doub
 // One thread per path of the round: pixel = pixels[k / ns], sample = base + k % ns.
 // raytrace_pixel's ray set-up, src/pathtracer/pathtracer.cpp:259-261, with
 // JitteredSampler2D::get_sample (src/pathtracer/sampler.cpp:14-18).
-__global__ void k_generate(FrameParams fp, DevScene S, PixView pv, uint32_t p0, const Ctl *ctl, int32_t sample_base,
-                           int32_t ns, RayQ q, PathBuf pb) {
+__global__ void k_generate(FrameParams fp, DevScene S, PixView pv, uint32_t p0, Ctl *ctl, RoundPlan rp, RayQ q, PathBuf pb) {
   const uint32_t stride = gridDim.x * blockDim.x;
   const uint32_t n_paths = ctl->n_cur;
+  const int32_t ns = rp.ns;
+  unsigned long long dead = 0;
   for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n_paths; k += stride) {
     const int32_t pix = pv.at(p0 + k / (uint32_t)ns);
-    const int32_t s = sample_base + (int32_t)(k % (uint32_t)ns);
+    int32_t first;
+    const int32_t planned = rp.planned(rp.state + (size_t)pix * 6, first);
+    const int32_t sk = (int32_t)(k % (uint32_t)ns);
+    q.path[k] = (int32_t)k;
+    pb.rad[0][k] = 0; pb.rad[1][k] = 0; pb.rad[2][k] = 0;
+    if (pb.pend[0]) { pb.pend[0][k] = 0; pb.pend[1][k] = 0; pb.pend[2][k] = 0; }
+    if (sk >= planned) {
+      // a slot this round does not use: a zero direction tells k_extend to skip it
+      q.d[0][k] = 0; q.d[1][k] = 0; q.d[2][k] = 0;
+      dead++;
+      continue;
+    }
+    const int32_t s = first + sk;
     const int32_t x = pix % fp.w, y = pix / fp.w;
     uint32_t wd[4];
     philox4x32_10((uint32_t)s, 0u, fp.seed_hi, 0u, fp.seed_lo, (uint32_t)pix, wd);
@@ -678,12 +733,11 @@ __global__ void k_generate(FrameParams fp, DevScene S, PixView pv, uint32_t p0, 
     const double sxp = (double)x + js[0], syp = (double)y + js[1];
     v3 o, d;
     camera_ray(fp, sxp / (double)fp.w, syp / (double)fp.h, o, d);
-    q.path[k] = (int32_t)k;
     q.o[0][k] = o.x; q.o[1][k] = o.y; q.o[2][k] = o.z;
     q.d[0][k] = d.x; q.d[1][k] = d.y; q.d[2][k] = d.z;
-    pb.rad[0][k] = 0; pb.rad[1][k] = 0; pb.rad[2][k] = 0;
-    if (pb.pend[0]) { pb.pend[0][k] = 0; pb.pend[1][k] = 0; pb.pend[2][k] = 0; }
   }
+  for (int off = 32; off > 0; off >>= 1) dead += __shfl_down(dead, off);
+  if ((threadIdx.x & 63) == 0 && dead) atomicAdd(&ctl->st_dead, dead);
 }
 
 // camera rays through caller-given sensor positions (ptamd_trace_primary)
@@ -703,17 +757,24 @@ __global__ void k_generate_primary(FrameParams fp, const double *__restrict__ sx
 // list position, light sample q of vertex i at slot i*nls + q) and the queues are
 // ordered index lists built by ballot / prefix-sum compaction: no atomics, and
 // the order is the same on every run.
+constexpr int32_t PRIM_UNUSED = -2;  // hit record of a path slot that holds no ray
 struct ExtendPolicy {
   RayQ q;
   const int32_t *list;
   HitBuf hb;
   double min_t, max_t;
-  __device__ __forceinline__ void load(uint32_t i, v3 &o, v3 &d, double &tmin, double &tmax) const {
+  // false: the slot holds no ray (see k_generate); its hit record says so
+  __device__ __forceinline__ bool load(uint32_t i, v3 &o, v3 &d, double &tmin, double &tmax) const {
     const uint32_t j = list ? (uint32_t)list[i] : i;
-    o = V(q.o[0][j], q.o[1][j], q.o[2][j]);
     d = V(q.d[0][j], q.d[1][j], q.d[2][j]);
+    if (!list && d.x == 0 && d.y == 0 && d.z == 0) {
+      hb.prim[i] = PRIM_UNUSED;
+      return false;
+    }
+    o = V(q.o[0][j], q.o[1][j], q.o[2][j]);
     tmin = min_t;
     tmax = max_t;
+    return true;
   }
   __device__ __forceinline__ void store(uint32_t i, const Hit &h, bool) const {
     hb.prim[i] = h.prim;
@@ -747,7 +808,7 @@ struct ShadowPolicy {
   ShadowQ sq;
   VertexBuf vb;
   uint32_t nls;
-  __device__ __forceinline__ void load(uint32_t i, v3 &o, v3 &d, double &tmin, double &tmax) const {
+  __device__ __forceinline__ bool load(uint32_t i, v3 &o, v3 &d, double &tmin, double &tmax) const {
     const int32_t slot = sq.slot[i];
     const uint32_t e = (uint32_t)slot / nls;
     o = V(vb.hp[0][e], vb.hp[1][e], vb.hp[2][e]);
@@ -755,6 +816,7 @@ struct ShadowPolicy {
     d = V(r.d[0], r.d[1], r.d[2]);
     tmin = PT_EPS_D;
     tmax = HEMI ? (double)INFINITY : r.max_t;
+    return true;
   }
   __device__ __forceinline__ void store(uint32_t i, const Hit &h, bool found) const {
     const int32_t slot = sq.slot[i];
@@ -874,12 +936,12 @@ struct Compact {
 template <bool HEMI>
 __global__ void __launch_bounds__(256)
     k_shade(FrameParams fp, DevScene S, RayQ q, const int32_t *__restrict__ list, HitBuf hb, RayQ qn, ShadowQ sq,
-            VertexBuf vb, PathBuf pb, Compact cp, Ctl *ctl, int32_t depth, PixView pv, uint32_t p0,
-            int32_t sample_base, int32_t ns) {
+            VertexBuf vb, PathBuf pb, Compact cp, Ctl *ctl, int32_t depth, PixView pv, uint32_t p0, RoundPlan rp) {
   __shared__ uint32_t wsum[2][4];
   const uint32_t n = ctl->n_cur;
   const uint32_t stride = gridDim.x * blockDim.x;
   const int nls = fp.nls;
+  const int ns = rp.ns;
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   for (uint32_t base_i = blockIdx.x * blockDim.x; base_i < n; base_i += stride) {
     const uint32_t i = base_i + threadIdx.x;
@@ -900,7 +962,7 @@ __global__ void __launch_bounds__(256)
       if (prim < 0) {
         // bounce ray left the scene: without accumulation the vertex before it
         // keeps its direct light (pathtracer.cpp:196-198)
-        if (!fp.accum && depth > 1) {
+        if (prim == -1 && !fp.accum && depth > 1) {
           pb.rad[0][path] += pb.pend[0][path];
           pb.rad[1][path] += pb.pend[1][path];
           pb.rad[2][path] += pb.pend[2][path];
@@ -957,7 +1019,7 @@ __global__ void __launch_bounds__(256)
           // the path's random numbers: key (seed, pixel), counter (sample, block)
           const uint32_t k = (uint32_t)path;
           rng_pix = (uint32_t)pv.at(p0 + k / (uint32_t)ns);
-          rng_s = (uint32_t)(sample_base + (int32_t)(k % (uint32_t)ns));
+          rng_s = (uint32_t)(rp.first_of(rp.state + (size_t)rng_pix * 6) + (int32_t)(k % (uint32_t)ns));
           rng_base = 1u + (uint32_t)(depth - 1) * (uint32_t)fp.bpv;
           uint32_t wd[4];
           philox4x32_10(rng_s, rng_base, fp.seed_hi, 0u, fp.seed_lo, rng_pix, wd);
@@ -1196,8 +1258,14 @@ __device__ __forceinline__ float illum(v3 v) { return (float)(0.2126f * v.x + 0.
 // traced for it so far (it did not stop at a test inside an earlier round) and the
 // test at i = n_done says so.
 __device__ __forceinline__ bool pixel_continues(const double *st, int32_t i, double tol);
-__device__ __forceinline__ bool pixel_survives(const double *st, int32_t n_done, double tol) {
-  return st[5] >= (double)n_done && pixel_continues(st, n_done, tol);
+// With n_done < 0 every pixel is judged at its own count, as the loop of
+// raytrace_pixel would: done at ns_aa samples, tested at every positive multiple
+// of the batch size.
+__device__ __forceinline__ bool pixel_survives(const double *st, int32_t n_done, double tol, int32_t batch, int32_t ns_aa) {
+  if (n_done >= 0) return st[5] >= (double)n_done && pixel_continues(st, n_done, tol);
+  const int32_t n = (int32_t)st[5];
+  if (n >= ns_aa) return false;
+  return n == 0 || n % batch != 0 || pixel_continues(st, n, tol);
 }
 __device__ __forceinline__ bool pixel_continues(const double *st, int32_t i, double tol) {
   const double s1 = st[0], s2 = st[1];
@@ -1213,20 +1281,21 @@ __device__ __forceinline__ bool pixel_continues(const double *st, int32_t i, dou
 // already computed. A round may hold several batches of a pixel, traced ahead of
 // their adaptive tests; the test runs here between the batches, and what was
 // traced past a pixel's stop is dropped. state: [pixel*6] = s1, s2, sum.rgb, n.
-__global__ void k_accumulate(PixView pv, uint32_t p0, Ctl *ctl, int32_t sample_base, int32_t ns, int32_t batch,
-                             double tol, PathBuf pb, double *__restrict__ state) {
+__global__ void k_accumulate(PixView pv, uint32_t p0, Ctl *ctl, RoundPlan rp, PathBuf pb, double *__restrict__ state) {
   const uint32_t stride = gridDim.x * blockDim.x;
   const uint32_t n_pixels = ctl->n_pix;
   unsigned long long kept = 0;
   for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n_pixels; p += stride) {
     double *st = state + (size_t)pv.at(p0 + p) * 6;
+    int32_t first;
+    const int32_t planned = rp.planned(st, first);
     double acc[2] = {st[0], st[1]};
     v3 sum = V(st[2], st[3], st[4]);
-    const size_t b = (size_t)p * (uint32_t)ns;
+    const size_t b = (size_t)p * (uint32_t)rp.ns;
     int s = 0;
-    for (; s < ns; s++) {
-      const int i = sample_base + s;
-      if (s > 0 && i % batch == 0 && !pixel_continues(acc, i, tol)) break;
+    for (; s < planned; s++) {
+      const int i = first + s;
+      if (s > 0 && i % rp.batch == 0 && !pixel_continues(acc, i, rp.tol)) break;
       const v3 L = V(pb.rad[0][b + s], pb.rad[1][b + s], pb.rad[2][b + s]);
       const double xl = illum(L);
       acc[0] += xl;
@@ -1243,12 +1312,12 @@ __global__ void k_accumulate(PixView pv, uint32_t p0, Ctl *ctl, int32_t sample_b
 
 // Ordered stream compaction of the still-active pixels, three small kernels:
 // per-block counts, scan of the counts, scatter.
-__global__ void k_filter_count(PixView pv, int32_t n_done, double tol, const double *__restrict__ state,
-                               uint32_t *__restrict__ block_count) {
+__global__ void k_filter_count(PixView pv, int32_t n_done, double tol, int32_t batch, int32_t ns_aa,
+                               const double *__restrict__ state, uint32_t *__restrict__ block_count) {
   __shared__ uint32_t wave_cnt[4];
   const uint32_t n = pv.count();
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool keep = i < n && pixel_survives(state + (size_t)pv.at(i) * 6, n_done, tol);
+  const bool keep = i < n && pixel_survives(state + (size_t)pv.at(i) * 6, n_done, tol, batch, ns_aa);
   const unsigned long long m = __ballot(keep);
   if (__lane_id() == 0) wave_cnt[threadIdx.x >> 6] = (uint32_t)__popcll(m);
   __syncthreads();
@@ -1278,12 +1347,13 @@ __global__ void k_filter_scan(uint32_t *block_count, uint32_t n_blocks, long lon
   }
   if (threadIdx.x == 0) *total_out = (long long)carry;
 }
-__global__ void k_filter_scatter(PixView pv, int32_t n_done, double tol, const double *__restrict__ state,
-                                 const uint32_t *__restrict__ block_offset, int32_t *__restrict__ out) {
+__global__ void k_filter_scatter(PixView pv, int32_t n_done, double tol, int32_t batch, int32_t ns_aa,
+                                 const double *__restrict__ state, const uint32_t *__restrict__ block_offset,
+                                 int32_t *__restrict__ out) {
   __shared__ uint32_t wave_cnt[4];
   const uint32_t n = pv.count();
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool keep = i < n && pixel_survives(state + (size_t)pv.at(i) * 6, n_done, tol);
+  const bool keep = i < n && pixel_survives(state + (size_t)pv.at(i) * 6, n_done, tol, batch, ns_aa);
   const unsigned long long m = __ballot(keep);
   const int lane = __lane_id(), wv = threadIdx.x >> 6;
   if (lane == 0) wave_cnt[wv] = (uint32_t)__popcll(m);
@@ -1936,7 +2006,8 @@ int ptamd_trace_list(ptamd_context *c, const ptamd_pixel_list *list, int32_t sam
   int rc = check_list(list, "ptamd_trace_list");
   if (rc) return rc;
   const int64_t n = shard_max(list);
-  if (n_samples <= 0 || sample_base < 0 || (n > 0 && !d_state)) {
+  if (n_samples <= 0 || sample_base < -1 || (n > 0 && !d_state) ||
+      (sample_base < 0 && n_samples % c->params.samples_per_batch != 0)) {
     ptamd::set_error("invalid arguments to ptamd_trace_list");
     return PTAMD_ERR_ARG;
   }
@@ -1963,13 +2034,16 @@ int ptamd_trace_list(ptamd_context *c, const ptamd_pixel_list *list, int32_t sam
   PathBuf pb = c->pb;
   if (fp.accum) pb.pend[0] = pb.pend[1] = pb.pend[2] = nullptr;
   const PixView pv = view_of(list);
+  // per-pixel prediction only where a launch is big enough for dropped samples to cost time
+  const RoundPlan rp{d_state, c->params.max_tolerance, sample_base, n_samples, c->params.samples_per_batch, c->params.ns_aa,
+                     n * n_samples >= (1 << 20) ? 1 : 0};
   Launcher L{c, s};
   const int depths = std::max(1, fp.max_ray_depth);
   for (int64_t p0 = 0; p0 < n; p0 += px_per_chunk) {
     const uint32_t up0 = (uint32_t)p0;
     L.begin(PTAMD_K_GENERATE);
     hipLaunchKernelGGL(k_set_counts, 1, 1, 0, s, c->ctl, pv, up0, (uint32_t)px_per_chunk, (uint32_t)n_samples);
-    hipLaunchKernelGGL(k_generate, ggrid, 256, 0, s, fp, c->S, pv, up0, c->ctl, sample_base, n_samples, c->q[0], pb);
+    hipLaunchKernelGGL(k_generate, ggrid, 256, 0, s, fp, c->S, pv, up0, c->ctl, rp, c->q[0], pb);
     L.end();
     int cur = 0;
     for (int depth = 1; depth <= depths; depth++) {
@@ -1985,10 +2059,10 @@ int ptamd_trace_list(ptamd_context *c, const ptamd_pixel_list *list, int32_t sam
       L.begin(PTAMD_K_SHADE);
       if (fp.hemisphere)
         hipLaunchKernelGGL(k_shade<true>, ggrid, 256, 0, s, fp, c->S, c->q[cur], lst, c->hb, c->q[cur ^ 1], c->sq, vb, pb,
-                           c->cp, c->ctl, depth, pv, up0, sample_base, n_samples);
+                           c->cp, c->ctl, depth, pv, up0, rp);
       else
         hipLaunchKernelGGL(k_shade<false>, ggrid, 256, 0, s, fp, c->S, c->q[cur], lst, c->hb, c->q[cur ^ 1], c->sq, vb, pb,
-                           c->cp, c->ctl, depth, pv, up0, sample_base, n_samples);
+                           c->cp, c->ctl, depth, pv, up0, rp);
       L.end();
       L.begin(PTAMD_K_OTHER);
       hipLaunchKernelGGL(k_scan2, 1, 1024, 0, s, c->cp, c->ctl);
@@ -2016,8 +2090,7 @@ int ptamd_trace_list(ptamd_context *c, const ptamd_pixel_list *list, int32_t sam
       cur ^= 1;
     }
     L.begin(PTAMD_K_ACCUMULATE);
-    hipLaunchKernelGGL(k_accumulate, ggrid, 256, 0, s, pv, up0, c->ctl, sample_base, n_samples,
-                       c->params.samples_per_batch, c->params.max_tolerance, pb, d_state);
+    hipLaunchKernelGGL(k_accumulate, ggrid, 256, 0, s, pv, up0, c->ctl, rp, pb, d_state);
     L.end();
   }
   HIPCHK(hipGetLastError());
@@ -2037,7 +2110,7 @@ int ptamd_filter_list(ptamd_context *c, const ptamd_pixel_list *in, int32_t n_do
   int rc = check_list(in, "ptamd_filter_list");
   if (rc) return rc;
   const int64_t n = shard_max(in);
-  if (n_done < 2 || !d_n_out || (n > 0 && (!d_out || !d_state))) {
+  if ((n_done < 2 && n_done != -1) || !d_n_out || (n > 0 && (!d_out || !d_state))) {
     ptamd::set_error("invalid arguments to ptamd_filter_list");
     return PTAMD_ERR_ARG;
   }
@@ -2052,9 +2125,11 @@ int ptamd_filter_list(ptamd_context *c, const ptamd_pixel_list *in, int32_t n_do
   const PixView pv = view_of(in);
   Launcher L{c, s};
   L.begin(PTAMD_K_FILTER);
-  if (nb) hipLaunchKernelGGL(k_filter_count, nb, 256, 0, s, pv, n_done, c->params.max_tolerance, d_state, c->block_count);
+  if (nb) hipLaunchKernelGGL(k_filter_count, nb, 256, 0, s, pv, n_done, c->params.max_tolerance, c->params.samples_per_batch,
+                             c->params.ns_aa, d_state, c->block_count);
   hipLaunchKernelGGL(k_filter_scan, 1, 1024, 0, s, c->block_count, nb, (long long *)d_n_out);
-  if (nb) hipLaunchKernelGGL(k_filter_scatter, nb, 256, 0, s, pv, n_done, c->params.max_tolerance, d_state, c->block_count, d_out);
+  if (nb) hipLaunchKernelGGL(k_filter_scatter, nb, 256, 0, s, pv, n_done, c->params.max_tolerance, c->params.samples_per_batch,
+                             c->params.ns_aa, d_state, c->block_count, d_out);
   L.end();
   HIPCHK(hipGetLastError());
   return PTAMD_OK;
@@ -2124,7 +2199,7 @@ int ptamd_get_stats(ptamd_context *c, ptamd_stats *out) {
   if (c->ctl) {
     Ctl h;
     HIPCHK(hipMemcpy(&h, c->ctl, sizeof h, hipMemcpyDeviceToHost));
-    c->stats.rays = h.st_rays;
+    c->stats.rays = h.st_rays - h.st_dead;  // path slots a round left unused are not rays
     c->stats.shadow_rays = h.st_shadow;
     c->stats.path_vertices = h.st_vertices;
     c->stats.nodes_visited = h.st_nodes;

@@ -70,7 +70,7 @@ class PixelSchedule:
 
 
 def render_frame(dev, params, rank=0, world=1, group=None, device=None, record_rounds=None, lag=1,
-                 pixel_stride=1, target_paths=16 << 20, max_batches=32):
+                 pixel_stride=1, target_paths=16 << 20, max_batches=32, per_pixel=False):
     """Renders one frame; returns (hdr[h,w,3], count[h,w]) as tensors on `device`, on every rank.
 
     dev: api.Device with scene and camera set. With world > 1 the default process
@@ -88,6 +88,11 @@ def render_frame(dev, params, rank=0, world=1, group=None, device=None, record_r
 
     target_paths, max_batches: see PixelSchedule.batches (max_batches = 1 keeps to
     one batch per round, the reference's own cadence).
+
+    per_pixel: every pixel continues from its own sample count and is traced ahead
+    only as far as its running statistics predict it will need (trace_list with
+    sample_base = -1), instead of all pixels of a round moving in lockstep. Same
+    frame; fewer samples traced and then dropped when a rank's rounds are small.
 
     pixel_stride = K renders only every K-th pixel of the rectangle (the others stay
     black): one GPU then does the work one rank of K would do, which is how the
@@ -116,12 +121,16 @@ def render_frame(dev, params, rank=0, world=1, group=None, device=None, record_r
         rows_recv = torch.empty((world * m0, 6), dtype=torch.float64, device=device)
     dev.frame_begin(params)
     cur, done, bound = 0, 0, n0
+    batch = params.samples_per_batch
+    # per_pixel: `done` is the least count any listed pixel can have (a pixel gains at
+    # least one batch per round), which bounds the number of rounds
     while done < params.ns_aa and bound > 0:
         if done > 0:
-            # the adaptive test of raytrace_pixel at i = done; every rank holds the
-            # whole state, so every rank computes the same survivor list
+            # the adaptive test of raytrace_pixel at i = done (per_pixel: at each pixel's own
+            # count); every rank holds the whole state, so every rank computes the same survivor list
             whole = cabi.PixelList(bufs[cur].data_ptr(), n_dev[cur:].data_ptr(), 0, bound, 0, 1)
-            dev.filter_list(whole, done, state.data_ptr(), bufs[cur ^ 1].data_ptr(), n_dev[cur ^ 1:].data_ptr(), stream)
+            dev.filter_list(whole, -1 if per_pixel else done, state.data_ptr(), bufs[cur ^ 1].data_ptr(),
+                            n_dev[cur ^ 1:].data_ptr(), stream)
             cur ^= 1
             host_n = torch.empty(1, dtype=torch.int64, pin_memory=on_gpu)
             host_n.copy_(n_dev[cur:cur + 1], non_blocking=True)
@@ -137,15 +146,15 @@ def render_frame(dev, params, rank=0, world=1, group=None, device=None, record_r
                 bound = min(bound, int(t.item()))
             if bound == 0:
                 break
-        ns = min(params.samples_per_batch * PixelSchedule.batches(bound, world, params.samples_per_batch,
-                                                                  params.ns_aa - done, target_paths, max_batches,
-                                                                  first=(done == 0)),
-                 params.ns_aa - done)
+        ns = batch * PixelSchedule.batches(bound, world, batch, params.ns_aa - done, target_paths, max_batches,
+                                           first=(done == 0))
+        if not per_pixel:
+            ns = min(ns, params.ns_aa - done)
         whole = cabi.PixelList(bufs[cur].data_ptr(), n_dev[cur:].data_ptr(), 0, bound, 0, 1)
         mine = cabi.PixelList(bufs[cur].data_ptr(), n_dev[cur:].data_ptr(), 0, bound, rank, world)
         if record_rounds is not None:
             record_rounds.append((done, bound, PixelSchedule.shard_size(bound, rank, world)))
-        dev.trace_list(mine, done, ns, state.data_ptr(), stream)
+        dev.trace_list(mine, -1 if per_pixel else done, ns, state.data_ptr(), stream)
         if world > 1:
             # every rank's updated rows to every rank: pack, one all-gather, unpack
             m = PixelSchedule.padded(bound, world)
@@ -159,7 +168,7 @@ def render_frame(dev, params, rank=0, world=1, group=None, device=None, record_r
             else:
                 dist.all_gather_into_tensor(recv, send, group=group)
             dev.unpack_rows(whole, world, rank, recv.data_ptr(), m, state.data_ptr(), stream)
-        done += ns
+        done += batch if per_pixel else ns
     hdr = torch.empty(npix * 3, dtype=torch.float64, device=device)
     cnt = torch.empty(npix, dtype=torch.int32, device=device)
     dev.frame_resolve(state.data_ptr(), hdr.data_ptr(), cnt.data_ptr(), stream)

@@ -49,8 +49,11 @@ class OracleDevice:
         for px in pix:
             x, y = int(px) % p.w, int(px) // p.w
             kept = 0
-            for s in range(sample_base, sample_base + n_samples):
-                if s > sample_base and s % p.samples_per_batch == 0 and not self._continues(st[px], s, p.max_tolerance):
+            # sample_base < 0: the pixel goes on from its own count (this stand-in plans
+            # no further than the device's upper limit; the frame does not depend on the plan)
+            first = sample_base if sample_base >= 0 else int(st[px, 5])
+            for s in range(first, min(first + n_samples, p.ns_aa if sample_base < 0 else first + n_samples)):
+                if s > first and s % p.samples_per_batch == 0 and not self._continues(st[px], s, p.max_tolerance):
                     break
                 kept += 1
                 O.lib().oracle_sample_radiance(C.byref(self.scene.desc), C.byref(self.cam), C.byref(p), x, y, s, rgb)
@@ -82,7 +85,12 @@ class OracleDevice:
         k = 0
         i = n_done
         for px in pin:
-            if st[px, 5] >= i and self._continues(st[px], i, p.max_tolerance):
+            if i >= 0:
+                keep = st[px, 5] >= i and self._continues(st[px], i, p.max_tolerance)
+            else:  # judged at the pixel's own count
+                n = int(st[px, 5])
+                keep = n < p.ns_aa and (n == 0 or n % p.samples_per_batch != 0 or self._continues(st[px], n, p.max_tolerance))
+            if keep:
                 out[k] = px
                 k += 1
         self._view(d_n_out, 1, np.int64)[0] = k
@@ -147,7 +155,8 @@ def _worker_body(rank, world, port, q):
     traced = dev.traced
     # the pipelined schedule (bounds one round old) must give the same frame, and so
     # must rounds that trace several batches ahead of their adaptive tests
-    for kw in (dict(lag=1, max_batches=1), dict(lag=1), dict(lag=0, max_batches=2)):
+    for kw in (dict(lag=1, max_batches=1), dict(lag=1), dict(lag=0, max_batches=2), dict(lag=1, per_pixel=True),
+               dict(lag=0, max_batches=2, per_pixel=True)):
         hdr_l, cnt_l = distributed.render_frame(dev, p, rank=rank, world=world, device=cpu, **kw)
         assert torch.equal(hdr_l, hdr) and torch.equal(cnt_l, cnt), "%r: frame differs" % (kw,)
     q.put((rank, hdr.numpy().copy(), cnt.numpy().copy(), rounds, traced))

@@ -39,16 +39,21 @@ def test_render_frame_pipelined_equals_synchronous_equals_render(device):
     assert np.array_equal(hdr_r, hdr_b) and np.array_equal(cnt_r, cnt_b)
     assert device.stats().samples == int(cnt_b.sum()), "only the samples that were kept count"
     for kw in (dict(lag=1, max_batches=1), dict(lag=2, max_batches=1), dict(lag=1), dict(lag=0, max_batches=2),
-               dict(lag=1, max_batches=4, target_paths=200000)):
+               dict(lag=1, max_batches=4, target_paths=200000),
+               # every pixel from its own count, traced ahead as far as its statistics predict
+               dict(lag=1, per_pixel=True), dict(lag=0, max_batches=2, per_pixel=True),
+               dict(lag=2, max_batches=6, target_paths=400000, per_pixel=True)):
         rounds = []
         hdr, cnt = distributed.render_frame(device, p, device=cuda, record_rounds=rounds, **kw)
         assert np.array_equal(hdr.cpu().numpy(), hdr_b) and np.array_equal(cnt.cpu().numpy(), cnt_b), repr(kw)
         bounds = [b for _, b, _ in rounds]
         assert bounds == sorted(bounds, reverse=True)
-        assert device.stats().samples == int(cnt_b.sum())
+        st = device.stats()
+        assert st.samples == int(cnt_b.sum())
+        assert st.rays >= st.samples, "slots a round leaves unused are not rays"
 
 
-def _virtual_ranks_frame(dev, p, world, lag, max_batches=1, target_paths=3 << 20):
+def _virtual_ranks_frame(dev, p, world, lag, max_batches=1, target_paths=3 << 20, per_pixel=False):
     """render_frame's loop with `world` ranks played in turn on one GPU."""
     cuda = torch.device("cuda", 0)
     npix = p.w * p.h
@@ -63,7 +68,8 @@ def _virtual_ranks_frame(dev, p, world, lag, max_batches=1, target_paths=3 << 20
         if done > 0:
             whole = cabi.PixelList(bufs[cur].data_ptr(), n_dev[cur:].data_ptr(), 0, bound, 0, 1)
             # every rank holds the same state, so one filter stands for all of them
-            dev.filter_list(whole, done, states[0].data_ptr(), bufs[cur ^ 1].data_ptr(), n_dev[cur ^ 1:].data_ptr())
+            dev.filter_list(whole, -1 if per_pixel else done, states[0].data_ptr(), bufs[cur ^ 1].data_ptr(),
+                            n_dev[cur ^ 1:].data_ptr())
             cur ^= 1
             history.append(int(n_dev[cur].item()))
             if len(history) > lag:
@@ -71,17 +77,17 @@ def _virtual_ranks_frame(dev, p, world, lag, max_batches=1, target_paths=3 << 20
             if bound == 0:
                 break
         k = distributed.PixelSchedule.batches(bound, world, p.samples_per_batch, p.ns_aa - done, target_paths, max_batches)
-        ns = min(k * p.samples_per_batch, p.ns_aa - done)
+        ns = k * p.samples_per_batch if per_pixel else min(k * p.samples_per_batch, p.ns_aa - done)
         whole = cabi.PixelList(bufs[cur].data_ptr(), n_dev[cur:].data_ptr(), 0, bound, 0, 1)
         m = distributed.PixelSchedule.padded(bound, world)
         blocks = recv[:world * m]
         for r in range(world):
             mine = cabi.PixelList(bufs[cur].data_ptr(), n_dev[cur:].data_ptr(), 0, bound, r, world)
-            dev.trace_list(mine, done, ns, states[r].data_ptr())
+            dev.trace_list(mine, -1 if per_pixel else done, ns, states[r].data_ptr())
             dev.pack_rows(mine, states[r].data_ptr(), blocks[r * m:].data_ptr())
         for r in range(world):
             dev.unpack_rows(whole, world, r, blocks.data_ptr(), m, states[r].data_ptr())
-        done += ns
+        done += p.samples_per_batch if per_pixel else ns
     torch.cuda.synchronize()
     for r in range(1, world):
         assert torch.equal(states[r], states[0]), "rank %d holds a different frame state" % r
@@ -91,13 +97,15 @@ def _virtual_ranks_frame(dev, p, world, lag, max_batches=1, target_paths=3 << 20
     return hdr.view(p.h, p.w, 3).cpu().numpy(), cnt.view(p.h, p.w).cpu().numpy()
 
 
-@pytest.mark.parametrize("world,lag,max_batches", [(2, 0, 1), (3, 1, 1), (8, 1, 1), (2, 1, 2), (8, 0, 16)])
-def test_virtual_ranks_reproduce_the_single_gpu_frame(device, world, lag, max_batches):
+@pytest.mark.parametrize("world,lag,max_batches,per_pixel", [(2, 0, 1, False), (3, 1, 1, False), (8, 1, 1, False),
+                                                             (2, 1, 2, False), (8, 0, 16, False), (2, 1, 4, True),
+                                                             (8, 1, 16, True)])
+def test_virtual_ranks_reproduce_the_single_gpu_frame(device, world, lag, max_batches, per_pixel):
     """Sharding by (offset, stride) + pack / all-gather layout / unpack: bit-identical
     to one GPU for any number of ranks (RNG keys are per pixel and sample)."""
     p = _setup(device)
     hdr_r, cnt_r = device.render(p)
-    hdr, cnt = _virtual_ranks_frame(device, p, world, lag, max_batches)
+    hdr, cnt = _virtual_ranks_frame(device, p, world, lag, max_batches, per_pixel=per_pixel)
     assert np.array_equal(cnt, cnt_r) and np.array_equal(hdr, hdr_r)
 
 

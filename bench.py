@@ -126,7 +126,7 @@ def profiled_traffic(scene, kernel):
     workload (profiles/, separate FETCH_SIZE and WRITE_SIZE runs). FETCH_SIZE is in KiB and,
     on gfx950, counts 128-byte read requests as 64 bytes, hence the factor 2."""
     names = {"extend": "k_extend<false>", "shadow": "k_shadow<false, false>", "shade": "k_shade<false>",
-             "resolve": "k_resolve"}
+             "resolve": "k_resolve", "trace2": "k_trace2<false, false>"}
     import glob
     found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_summary.json" % scene)))
     if kernel not in names or not found:
@@ -192,16 +192,25 @@ def main():
                                             max_batches=args.max_batches, per_pixel=bool(args.per_pixel))
         return cnt
 
+    # Warm-up frames time every kernel class with HIP events and so find the dominant one; the timed
+    # steps then keep only that class's events (each event pair idles the GPU for ~10 us between two
+    # launches, 5 % of a frame when a rank of 8 runs 40 launches per ms-long round).
+    NK = len(cabi.K_NAMES)
+    warm_ms, dom = None, cabi.K_TRACE2
     for i in range(args.warmup):
         int(frame(1000 + i).sum().item())  # warm-up covers everything a timed step does
-        dev.stats()
+        st = dev.stats()
+        warm_ms = {cabi.K_NAMES[k]: st.kernel_ms[k] for k in range(NK) if st.launches[k]}
+        dom = max(range(NK), key=lambda k: st.kernel_ms[k])
+    if args.warmup:
+        dev.set_event_classes(1 << dom)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     total_samples = 0
-    agg = {"ms": [0.0] * 8, "launches": [0] * 8, "rays": 0, "shadow": 0, "vertices": 0}
+    agg = {"ms": [0.0] * NK, "launches": [0] * NK, "rays": 0, "shadow": 0, "vertices": 0, "two_ext": 0, "two_shadow": 0}
     step_ms = []
     for i in range(args.steps):
         ts = time.perf_counter()
@@ -210,12 +219,14 @@ def main():
         wall = 1000.0 * (time.perf_counter() - ts)
         st = dev.stats()  # this rank's share of the frame
         step_ms.append((wall, sum(st.kernel_ms)))
-        for k in range(8):
+        for k in range(NK):
             agg["ms"][k] += st.kernel_ms[k]
             agg["launches"][k] += st.launches[k]
         agg["rays"] += st.rays
         agg["shadow"] += st.shadow_rays
         agg["vertices"] += st.path_vertices
+        agg["two_ext"] += st.two_ext_rays
+        agg["two_shadow"] += st.two_shadow_rays
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -248,6 +259,7 @@ def main():
                 "samples_per_step": total_samples // max(args.steps, 1),
                 "parallelism": "pixels of each adaptive round dealt round-robin over %d GPU(s)" % world},
         }
+        dev.set_event_classes(0xffffffff)
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             try:
@@ -271,19 +283,30 @@ def main():
                 own = {"error": repr(e)}
         # ---- roofline of the dominant kernel (rank 0's launches)
         names = cabi.K_NAMES
-        dom = max(range(8), key=lambda k: agg["ms"][k])
+        if not args.warmup:
+            dom = max(range(NK), key=lambda k: agg["ms"][k])
         roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
                 "traffic": None, "kernel": names[dom],
-                "kernel_ms": {names[k]: agg["ms"][k] for k in range(8) if agg["launches"][k]},
-                "launches": {names[k]: agg["launches"][k] for k in range(8) if agg["launches"][k]}}
+                "kernel_ms": {names[k]: agg["ms"][k] for k in range(NK) if agg["ms"][k]},
+                "launches": {names[k]: agg["launches"][k] for k in range(NK) if agg["launches"][k]},
+                "kernel_ms_all_classes_warmup_frame": warm_ms}
         if cpu and "counts" in cpu:
             c = cpu["counts"]
             ext_rays = agg["rays"] - agg["shadow"]
             b_ext = 32 * c["V_ext"] + 36 * c["T_ext"] + 92
             b_sh = 32 * c["V_shadow"] + 36 * c["T_shadow"] + 92
-            if dom in (1, 3):
-                rays = ext_rays if dom == 1 else agg["shadow"]
-                b = b_ext if dom == 1 else b_sh
+            if dom in (1, 3, cabi.K_TRACE2):
+                # rays the dominant traversal kernel traced: k_extend the bounce and camera rays that did
+                # not go through k_trace2, k_shadow likewise, k_trace2 rays of both kinds in one launch
+                if dom == 1:
+                    rays, b = ext_rays - agg["two_ext"], b_ext
+                elif dom == 3:
+                    rays, b = agg["shadow"] - agg["two_shadow"], b_sh
+                else:
+                    rays = agg["two_ext"] + agg["two_shadow"]
+                    b = (agg["two_ext"] * b_ext + agg["two_shadow"] * b_sh) / max(rays, 1)
+                    roof["rays_per_launch_by_kind"] = {"bounce": agg["two_ext"] / max(agg["launches"][dom], 1),
+                                                       "shadow": agg["two_shadow"] / max(agg["launches"][dom], 1)}
                 ms = agg["ms"][dom]
                 ach = rays * b / (ms * 1e-3) / 1e9 if ms > 0 else None
                 roof.update({"achieved": ach, "frac": ach / HBM_PEAK_GBS if ach else None,

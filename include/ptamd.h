@@ -130,8 +130,10 @@ typedef struct ptamd_stats {
   uint64_t path_vertices;  /* shaded hits                                         */
   uint64_t nodes_visited;  /* BVH nodes popped (only when counters are enabled)   */
   uint64_t prim_tests;     /* primitive tests  (only when counters are enabled)   */
-  uint64_t launches[8];    /* kernel launches per kernel class                    */
-  double kernel_ms[8];     /* summed HIP-event time per kernel class (profiling)  */
+  uint64_t launches[12];   /* kernel launches per kernel class                    */
+  double kernel_ms[12];    /* summed HIP-event time per kernel class (profiling)  */
+  uint64_t two_ext_rays;   /* bounce rays traced by launches of class PTAMD_K_TRACE2 */
+  uint64_t two_shadow_rays;/* shadow rays traced by launches of class PTAMD_K_TRACE2 */
 } ptamd_stats;
 
 /* kernel classes for ptamd_stats.launches / kernel_ms */
@@ -143,6 +145,8 @@ typedef struct ptamd_stats {
 #define PTAMD_K_ACCUMULATE 5
 #define PTAMD_K_FILTER 6
 #define PTAMD_K_OTHER 7
+#define PTAMD_K_TRACE2 8 /* one launch: bounce rays of depth d + 1 and shadow rays of depth d */
+#define PTAMD_K_CLASSES 12
 
 typedef struct ptamd_scene ptamd_scene;     /* host scene (parsed + built) */
 typedef struct ptamd_context ptamd_context; /* one GPU                     */
@@ -180,6 +184,11 @@ int ptamd_set_camera(ptamd_context *ctx, const ptamd_camera *cam);
 int ptamd_set_max_paths(ptamd_context *ctx, int64_t max_paths);
 /* Enables per-launch HIP-event timing and traversal counters (slower). */
 int ptamd_set_profiling(ptamd_context *ctx, int32_t events, int32_t counters);
+/* Restricts the HIP events of ptamd_set_profiling to the kernel classes whose bit
+ * (1 << PTAMD_K_x) is set in `mask` (default: all). An event pair costs about
+ * 10 us of idle GPU between two launches, so a timed run records only the
+ * classes it reports. */
+int ptamd_set_event_classes(ptamd_context *ctx, uint32_t mask);
 
 /* Whole frame on this GPU: replaces render_to_file's start_raytracing +
  * wait-for-DONE (raytraced_renderer.cpp:331-336). hdr_out/count_out are HOST

@@ -15,7 +15,7 @@ EXPORTS = (
     "ptamd_last_error", "ptamd_scene_load", "ptamd_scene_free", "ptamd_scene_get_desc",
     "ptamd_scene_get_camera", "ptamd_scene_load_camera_file", "ptamd_scene_build_seconds",
     "ptamd_create", "ptamd_destroy", "ptamd_upload_scene", "ptamd_set_camera", "ptamd_set_max_paths",
-    "ptamd_set_profiling", "ptamd_render", "ptamd_trace_primary", "ptamd_frame_begin",
+    "ptamd_set_profiling", "ptamd_set_event_classes", "ptamd_render", "ptamd_trace_primary", "ptamd_frame_begin",
     "ptamd_trace_pixels", "ptamd_adaptive_filter", "ptamd_frame_resolve", "ptamd_get_stats",
     "ptamd_trace_list", "ptamd_filter_list", "ptamd_pack_rows", "ptamd_unpack_rows",
     "ptamd_tonemap_rgba8", "ptamd_write_png", "ptamd_write_png_top_down", "ptamd_sampling_rate_rgba8",
@@ -59,6 +59,7 @@ def lib():
     L.ptamd_set_camera.argtypes = [vp, C.POINTER(Camera)]
     L.ptamd_set_max_paths.argtypes = [vp, i64]
     L.ptamd_set_profiling.argtypes = [vp, i32, i32]
+    L.ptamd_set_event_classes.argtypes = [vp, C.c_uint32]
     L.ptamd_render.argtypes = [vp, C.POINTER(RenderParams), pd, pi]
     L.ptamd_trace_primary.argtypes = [vp, i64, pd, pd, pi, pd]
     L.ptamd_frame_begin.argtypes = [vp, C.POINTER(RenderParams)]
@@ -143,6 +144,10 @@ class Device:
 
     def set_profiling(self, events=False, counters=False):
         _check(lib().ptamd_set_profiling(self._h, int(events), int(counters)))
+
+    def set_event_classes(self, mask):
+        """Bit k of mask: launches of kernel class k are timed with HIP events."""
+        _check(lib().ptamd_set_event_classes(self._h, mask))
 
     def render(self, params):
         """Whole frame; returns (hdr[h,w,3] float64, count[h,w] int32), row 0 = bottom."""

@@ -6,7 +6,9 @@ import numpy as np
 PRIM_TRIANGLE, PRIM_SPHERE = 0, 1
 MAT_DIFFUSE, MAT_EMISSION, MAT_MIRROR, MAT_MICROFACET, MAT_REFRACTION, MAT_GLASS = range(6)
 LIGHT_DIRECTIONAL, LIGHT_INF_HEMISPHERE, LIGHT_POINT, LIGHT_SPOT, LIGHT_AREA = range(5)
-K_NAMES = ("generate", "extend", "shade", "shadow", "resolve", "accumulate", "filter", "other")
+K_NAMES = ("generate", "extend", "shade", "shadow", "resolve", "accumulate", "filter", "other", "trace2",
+           "class9", "class10", "class11")
+K_TRACE2 = 8
 
 _pi32 = C.POINTER(C.c_int32)
 _pf64 = C.POINTER(C.c_double)
@@ -50,7 +52,8 @@ class Stats(C.Structure):
     _fields_ = [("seconds", C.c_double), ("samples", C.c_uint64), ("rays", C.c_uint64),
                 ("shadow_rays", C.c_uint64), ("path_vertices", C.c_uint64),
                 ("nodes_visited", C.c_uint64), ("prim_tests", C.c_uint64),
-                ("launches", C.c_uint64 * 8), ("kernel_ms", C.c_double * 8)]
+                ("launches", C.c_uint64 * 12), ("kernel_ms", C.c_double * 12),
+                ("two_ext_rays", C.c_uint64), ("two_shadow_rays", C.c_uint64)]
 
 
 def make_params(w, h, ns_aa=1, max_ray_depth=1, accumulate_bounces=True, ns_area_light=1,

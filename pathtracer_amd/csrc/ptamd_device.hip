@@ -95,8 +95,9 @@ struct FrameParams {
 
 struct Ctl {
   uint32_t n_cur, n_next, n_shadow, n_pix;  // sizes of the ray lists; pixels of the running chunk
-  uint32_t grab[4];  // next unclaimed ray of the running extend / shadow kernel (persistent driver)
+  uint32_t grab[4];  // next unclaimed ray of a list: [0] k_extend, [1] shadow rays, [2] bounce rays in k_trace2 (persistent drivers)
   unsigned long long st_rays, st_shadow, st_vertices, st_nodes, st_tests, st_samples, st_dead;
+  unsigned long long st_two_ext, st_two_shadow;  // rays of either kind traced by k_trace2 launches
 };
 
 // A shard of a device-resident pixel list: entries offset, offset + stride, ...
@@ -219,8 +220,7 @@ struct RoundPlan {
 // Assumes scene coordinates and distances far from the ends of the float range
 // (|x| in [2^-60, 2^60]).
 struct RayF {
-  float of[3], inv[3], slack[3];
-  float m0;  // max(min_t rounded down, 0)
+  float inv[3];
 };
 __device__ __forceinline__ float f_down(double x) {
   float f = (float)x;
@@ -230,16 +230,11 @@ __device__ __forceinline__ float f_up(double x) {
   float f = (float)x;
   return ((double)f < x) ? nextafterf(f, INFINITY) : f;
 }
-__device__ __forceinline__ RayF make_rayf(v3 o, v3 d, double min_t) {
+__device__ __forceinline__ RayF make_rayf(v3 d) {
   RayF r;
-  r.of[0] = (float)o.x; r.of[1] = (float)o.y; r.of[2] = (float)o.z;
   r.inv[0] = __builtin_amdgcn_rcpf((float)d.x);
   r.inv[1] = __builtin_amdgcn_rcpf((float)d.y);
   r.inv[2] = __builtin_amdgcn_rcpf((float)d.z);
-  const float k = 2.38418579e-07f;  // 2^-22
-#pragma unroll
-  for (int a = 0; a < 3; a++) r.slack[a] = fabsf(r.of[a] * r.inv[a]) * k;
-  r.m0 = fmaxf(f_down(min_t), 0.f);
   return r;
 }
 
@@ -283,18 +278,33 @@ __device__ __forceinline__ RayF make_rayf(v3 o, v3 d, double min_t) {
 #endif
 #define TRAV_BOUNDS_N(n) __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(n, n)))
 constexpr int TRAV_BLOCK = 256;
+// (the LDS pointer carries its address space: as a generic pointer it made the gfx950
+// backend of ROCm 7.2 emit an invalid null check in the two-list kernel)
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __attribute__((address_space(3))) uint2 lds_uint2;
+#else
+typedef uint2 lds_uint2;  // the host pass only parses the device code
+#endif
 struct TravStack {
-  uint2 *lds;
+  lds_uint2 *lds;
   uint2 *glob;
   uint32_t gstride, gtid;
   int STACK_LDS;  // levels held in LDS
+  // (the global strip is accessed with non-temporal loads and stores so that the optimiser cannot
+  // merge the two branches into one access through a generic pointer)
   __device__ __forceinline__ void put(int level, uint2 e) const {
-    if (level < STACK_LDS) lds[level * TRAV_BLOCK + threadIdx.x] = e;
-    else glob[(size_t)(level - STACK_LDS) * gstride + gtid] = e;
+    if (level < STACK_LDS) {
+      lds[level * TRAV_BLOCK + threadIdx.x] = e;
+    } else {
+      uint32_t *g = reinterpret_cast<uint32_t *>(glob + ((size_t)(level - STACK_LDS) * gstride + gtid));
+      __builtin_nontemporal_store(e.x, g);
+      __builtin_nontemporal_store(e.y, g + 1);
+    }
   }
   __device__ __forceinline__ uint2 get(int level) const {
     if (level < STACK_LDS) return lds[level * TRAV_BLOCK + threadIdx.x];
-    return glob[(size_t)(level - STACK_LDS) * gstride + gtid];
+    const uint32_t *g = reinterpret_cast<const uint32_t *>(glob + ((size_t)(level - STACK_LDS) * gstride + gtid));
+    return make_uint2(__builtin_nontemporal_load(g), __builtin_nontemporal_load(g + 1));
   }
   // LDS-only forms; level STACK_LDS is the scratch slot
   __device__ __forceinline__ void put_lds(int level, uint2 e) const { lds[level * TRAV_BLOCK + threadIdx.x] = e; }
@@ -325,19 +335,25 @@ __device__ __forceinline__ void cswap(float &ta, int32_t &ca, float &tb, int32_t
 struct Walk {
   v3 o, d;
   RayF rf;
-  double min_t, max_t0, best_t;
+  double best_t;
   float best_f;
-  Hit hit;
+  // the hit so far; its distance is best_t (an accepted hit always shortens the ray to its own t,
+  // and without a hit both are the ray's max_t)
+  // Its barycentrics do not stay in registers: the policy's record() writes them to the hit buffer
+  // every time a closer hit is found (a ray finds about 1.5), which is cheaper than four registers.
+  int32_t hit_prim;
   int sp;
   int32_t cur;
+  __device__ __forceinline__ Hit result() const { return Hit{best_t, 0.0, 0.0, hit_prim}; }
 
-  __device__ __forceinline__ void begin(const DevScene &S, v3 o_, v3 d_, double tmin, double tmax) {
+  // (min_t is the same for every ray of a launch: the drivers hold it, and m0 = max(min_t rounded
+  // down, 0) for the box test, in scalar registers instead of two and one per lane)
+  __device__ __forceinline__ void begin(const DevScene &S, v3 o_, v3 d_, double tmax) {
     o = o_; d = d_;
-    rf = make_rayf(o, d, tmin);
-    min_t = tmin; max_t0 = tmax;
+    rf = make_rayf(d);
     best_t = tmax;
     best_f = f_up(tmax);
-    hit.prim = -1; hit.t = tmax; hit.u = 0; hit.v = 0;
+    hit_prim = -1;
     sp = 0;
     cur = S.root_code;
   }
@@ -366,19 +382,23 @@ struct Walk {
 
   // cur >= 0: test the node's four child boxes, descend into the nearest
   template <bool COUNT>
-  __device__ __forceinline__ void node_step(const DevScene &S, const TravStack &stack, uint32_t &n_nodes) {
+  __device__ __forceinline__ void node_step(const DevScene &S, const TravStack &stack, uint32_t &n_nodes, float m0) {
     const float FINF = INFINITY;
     const uint4 *np = reinterpret_cast<const uint4 *>(S.nodes + cur);
     const uint4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3];
     if (COUNT) n_nodes += 4;
     const float org[3] = {__uint_as_float(w0.x), __uint_as_float(w0.y), __uint_as_float(w0.z)};
+    // float(o) and the slack |of inv| 2^-22 are recomputed here rather than carried by the walk:
+    // six registers less per lane are worth more than the nine instructions
+    const float of[3] = {(float)o.x, (float)o.y, (float)o.z};
     float A[3], Blo[3], Bhi[3];
 #pragma unroll
     for (int a = 0; a < 3; a++) {
       const int e = (int)(w0.w << (24 - 8 * a)) >> 24;  // signed byte a
       A[a] = __builtin_ldexpf(rf.inv[a], e);
-      const float B = (org[a] - rf.of[a]) * rf.inv[a];
-      const float E = fmaf(fmaf(fabsf(A[a]), 255.f, fabsf(B)), 9.53674316e-07f /* 2^-20 */, rf.slack[a]);
+      const float B = (org[a] - of[a]) * rf.inv[a];
+      const float slack = fabsf(of[a] * rf.inv[a]) * 2.38418579e-07f;  // 2^-22
+      const float E = fmaf(fmaf(fabsf(A[a]), 255.f, fabsf(B)), 9.53674316e-07f /* 2^-20 */, slack);
       const float cE = copysignf(E, A[a]);
       Blo[a] = B - cE;
       Bhi[a] = B + cE;
@@ -402,7 +422,7 @@ struct Walk {
       }
       // bbox.cpp:38 with NaNs (dropped above) accepting: reject iff
       // max(tn, min_t, 0) > min(tf, max_t)
-      const float lo2 = fmaxf(tn, rf.m0), hi2 = fminf(tf, best_f);
+      const float lo2 = fmaxf(tn, m0), hi2 = fminf(tf, best_f);
       t[k] = (c[k] != CHILD_EMPTY && !(lo2 > hi2)) ? lo2 : FINF;
     }
     cswap(t[0], c[0], t[1], c[1]);
@@ -430,9 +450,12 @@ struct Walk {
     }
   }
 
-  // cur is a primitive: the reference's FP64 test; returns true when the walk is over
-  template <bool ANY, bool COUNT>
-  __device__ __forceinline__ bool prim_step(const DevScene &S, const TravStack &stack, uint32_t &n_tests) {
+  // cur is a primitive: the reference's FP64 test; returns true when the walk is over.
+  // ANY: 0 closest hit, 1 first hit, 2 per ray (`first_hit`)
+  // rec(u, v): called when a hit is recorded as the closest so far
+  template <int ANY, bool COUNT, class Rec>
+  __device__ __forceinline__ bool prim_step(const DevScene &S, const TravStack &stack, uint32_t &n_tests, double min_t,
+                                            const Rec &rec, bool first_hit = false) {
     const int p = (int)~(uint32_t)cur;
     if (COUNT) n_tests++;
     const double *P = S.prim + (size_t)p * PRIM_STRIDE;
@@ -471,10 +494,12 @@ struct Walk {
       // (r.max_t = t); it is RECORDED when strictly closer than anything before
       // (bvh.cpp:187), or equally close as the recorded hit but earlier in the
       // reference's visiting order (lower index here).
-      if (ANY) {
-        if (t < max_t0) { hit.prim = p; hit.t = t; return true; }
-      } else if (t < best_t || (hit.prim >= 0 && p < hit.prim)) {
-        hit.prim = p; hit.t = t; hit.u = u; hit.v = v;
+      if (ANY == 1 || (ANY == 2 && first_hit)) {
+        // (best_t is still the ray's own max_t: a first-hit walk ends at its first hit)
+        if (t < best_t) { hit_prim = p; best_t = t; return true; }
+      } else if (t < best_t || (hit_prim >= 0 && p < hit_prim)) {
+        hit_prim = p;
+        rec(u, v);
       }
       best_t = t;
       best_f = f_up(t);
@@ -484,7 +509,7 @@ struct Walk {
   }
 };
 
-// Traces a list of rays. Policy: load(i, o, d, min_t, max_t) reads ray i;
+// Traces a list of rays. Policy: load(i, o, d, max_t) reads ray i, min_t_all() is the min_t of all of them;
 // store(i, hit, found) writes its result. One trip of the walk: PTAMD_NODE_STEPS
 // box steps for the lanes at a node, then a primitive test for the lanes at a
 // primitive (which includes lanes a box step just brought there). Running the two
@@ -512,24 +537,28 @@ struct Walk {
 #ifndef PTAMD_GRAB
 #define PTAMD_GRAB 256
 #endif
-template <bool ANY, bool COUNT, int REFILL, class Policy>
+template <int ANY, bool COUNT, int REFILL, class Policy>
 __device__ __forceinline__ void trace_rays(const DevScene &S, const Policy &pol, uint32_t n, uint32_t *grab,
                                            const TravStack &stack, uint32_t &n_nodes, uint32_t &n_tests) {
   Walk w;
+  const double min_t = pol.min_t_all();
+  const float m0 = fmaxf(f_down(min_t), 0.f);
   if (REFILL == 0) {
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
       v3 o, d;
-      double tmin, tmax;
-      if (!pol.load(i, o, d, tmin, tmax)) continue;
-      w.begin(S, o, d, tmin, tmax);
+      double tmax;
+      if (!pol.load(i, o, d, tmax)) continue;
+      w.begin(S, o, d, tmax);
       while (w.cur != CHILD_EMPTY) {
 #pragma unroll
         for (int k = 0; k < PTAMD_NODE_STEPS; k++)
-          if (w.cur >= 0) w.template node_step<COUNT>(S, stack, n_nodes);
-        if (w.cur < 0 && w.cur != CHILD_EMPTY && w.template prim_step<ANY, COUNT>(S, stack, n_tests)) break;
+          if (w.cur >= 0) w.template node_step<COUNT>(S, stack, n_nodes, m0);
+        if (w.cur < 0 && w.cur != CHILD_EMPTY &&
+            w.template prim_step<ANY, COUNT>(S, stack, n_tests, min_t, [&](double u, double v) { pol.record(i, u, v); }))
+          break;
       }
-      pol.store(i, w.hit, w.hit.prim >= 0);
+      pol.store(i, w.result(), w.hit_prim >= 0);
     }
     return;
   }
@@ -560,9 +589,9 @@ __device__ __forceinline__ void trace_rays(const DevScene &S, const Policy &pol,
         if (!active && mine < end) {
           idx = mine;
           v3 o, d;
-          double tmin, tmax;
-          if (pol.load(idx, o, d, tmin, tmax)) {
-            w.begin(S, o, d, tmin, tmax);
+          double tmax;
+          if (pol.load(idx, o, d, tmax)) {
+            w.begin(S, o, d, tmax);
             active = true;
           }
         }
@@ -576,11 +605,98 @@ __device__ __forceinline__ void trace_rays(const DevScene &S, const Policy &pol,
     if (active) {
 #pragma unroll
       for (int k = 0; k < PTAMD_NODE_STEPS; k++)
-        if (w.cur >= 0) w.template node_step<COUNT>(S, stack, n_nodes);
+        if (w.cur >= 0) w.template node_step<COUNT>(S, stack, n_nodes, m0);
       bool done = w.cur == CHILD_EMPTY;
-      if (!done && w.cur < 0) done = w.template prim_step<ANY, COUNT>(S, stack, n_tests) || w.cur == CHILD_EMPTY;
+      if (!done && w.cur < 0)
+        done = w.template prim_step<ANY, COUNT>(S, stack, n_tests, min_t, [&](double u, double v) { pol.record(idx, u, v); }) ||
+               w.cur == CHILD_EMPTY;
       if (done) {
-        pol.store(idx, w.hit, w.hit.prim >= 0);
+        pol.store(idx, w.result(), w.hit_prim >= 0);
+        active = false;
+      }
+    }
+  }
+}
+
+// Two ray lists in one launch of persistent waves: list E (closest-hit rays, policy
+// pe) is claimed first, then list S (policy ps; first-hit rays unless CLOSEST_S).
+// Every traversal launch ends with a phase in which a few long walks keep a few
+// lanes busy and the rest of the GPU idles: about 0.25 ms for closest-hit rays on
+// a 100k-triangle scene, however short the list. The bounce rays of depth d + 1
+// and the shadow rays of depth d are both ready once depth d has been shaded, so
+// they are traced together: the shadow rays fill the lanes the long bounce-ray
+// walks leave idle, and a depth costs one such phase instead of two.
+template <bool CLOSEST_S, bool COUNT, int REFILL, class PolE, class PolS>
+__device__ __forceinline__ void trace_two_lists(const DevScene &S, const PolE &pe, uint32_t n_e, uint32_t *grab_e,
+                                                const PolS &ps, uint32_t n_s, uint32_t *grab_s, const TravStack &stack,
+                                                uint32_t &n_nodes, uint32_t &n_tests) {
+  Walk w;
+  const double min_t = pe.min_t_all();  // == ps.min_t_all(): both kinds of ray leave a surface
+  const float m0 = fmaxf(f_down(min_t), 0.f);
+  const uint32_t waves = gridDim.x * (TRAV_BLOCK / 64u);
+  const uint32_t pw_e = n_e / waves, pw_s = n_s / waves;
+  const uint32_t g_e = pw_e >= PTAMD_GRAB ? PTAMD_GRAB : (pw_e < 64u ? 64u : (pw_e & ~63u));
+  const uint32_t g_s = pw_s >= PTAMD_GRAB ? PTAMD_GRAB : (pw_s < 64u ? 64u : (pw_s & ~63u));
+  const int lane = threadIdx.x & 63;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  uint32_t next = 0, end = 0, idx = 0;
+  int phase = 0;  // list being claimed: 0 = E, 1 = S, 2 = both are handed out (wave-uniform)
+  bool active = false, from_s = false;
+  w.cur = CHILD_EMPTY;
+  w.sp = 0;
+  for (;;) {
+    const unsigned long long idle = __ballot(!active);
+    const int n_idle = __popcll(idle);
+    if (n_idle >= REFILL && phase < 2) {
+      if (next >= end) {
+        uint32_t base = 0, n, g;
+        if (phase == 0) {
+          n = n_e; g = g_e;
+          if (lane == 0) base = atomicAdd(grab_e, g_e);
+        } else {
+          n = n_s; g = g_s;
+          if (lane == 0) base = atomicAdd(grab_s, g_s);
+        }
+        base = (uint32_t)__shfl((int)base, 0);
+        if (base >= n) {  // this list is handed out: on to the next one
+          phase++;
+          next = end = 0;
+          continue;
+        }
+        next = base;
+        end = base + g < n ? base + g : n;
+      }
+      const uint32_t mine = next + (uint32_t)__popcll(idle & below);
+      if (!active && mine < end) {
+        idx = mine;
+        v3 o, d;
+        double tmax;
+        const bool have = phase == 0 ? pe.load(idx, o, d, tmax) : ps.load(idx, o, d, tmax);
+        if (have) {
+          w.begin(S, o, d, tmax);
+          active = true;
+          from_s = phase == 1;
+        }
+      }
+      next = next + (uint32_t)n_idle < end ? next + (uint32_t)n_idle : end;
+    }
+    if (!__ballot(active)) {
+      if (phase >= 2) break;  // every wave gets here: both lists are finite and claimed monotonically
+      continue;
+    }
+    if (active) {
+#pragma unroll
+      for (int k = 0; k < PTAMD_NODE_STEPS; k++)
+        if (w.cur >= 0) w.template node_step<COUNT>(S, stack, n_nodes, m0);
+      bool done = w.cur == CHILD_EMPTY;
+      if (!done && w.cur < 0)
+        done = w.template prim_step<2, COUNT>(S, stack, n_tests, min_t,
+                                              [&](double u, double v) { if (!from_s) pe.record(idx, u, v); },
+                                              !CLOSEST_S && from_s) ||
+               w.cur == CHILD_EMPTY;
+      if (done) {
+        if (from_s) ps.store(idx, w.result(), w.hit_prim >= 0);
+        else pe.store(idx, w.result(), w.hit_prim >= 0);
         active = false;
       }
     }
@@ -678,7 +794,7 @@ __global__ void k_set_counts(Ctl *ctl, PixView pv, uint32_t p0, uint32_t chunk, 
   ctl->n_cur = np * ns;
   ctl->n_next = 0;
   ctl->n_shadow = 0;
-  ctl->grab[0] = ctl->grab[1] = 0;
+  ctl->grab[0] = ctl->grab[1] = ctl->grab[2] = 0;
 }
 
 // end of one depth: fold the stage's counts into the statistics, make the next
@@ -689,7 +805,7 @@ __global__ void k_advance(Ctl *ctl) {
   ctl->n_cur = ctl->n_next;
   ctl->n_next = 0;
   ctl->n_shadow = 0;
-  ctl->grab[0] = ctl->grab[1] = 0;
+  ctl->grab[0] = ctl->grab[1] = ctl->grab[2] = 0;
 }
 
 // Camera::generate_ray, src/pathtracer/camera.cpp:190-203
@@ -763,8 +879,9 @@ struct ExtendPolicy {
   const int32_t *list;
   HitBuf hb;
   double min_t, max_t;
+  __device__ __forceinline__ double min_t_all() const { return min_t; }
   // false: the slot holds no ray (see k_generate); its hit record says so
-  __device__ __forceinline__ bool load(uint32_t i, v3 &o, v3 &d, double &tmin, double &tmax) const {
+  __device__ __forceinline__ bool load(uint32_t i, v3 &o, v3 &d, double &tmax) const {
     const uint32_t j = list ? (uint32_t)list[i] : i;
     d = V(q.d[0][j], q.d[1][j], q.d[2][j]);
     if (!list && d.x == 0 && d.y == 0 && d.z == 0) {
@@ -772,15 +889,17 @@ struct ExtendPolicy {
       return false;
     }
     o = V(q.o[0][j], q.o[1][j], q.o[2][j]);
-    tmin = min_t;
     tmax = max_t;
     return true;
   }
+  __device__ __forceinline__ void record(uint32_t i, double u, double v) const {
+    hb.u[i] = u;
+    hb.v[i] = v;
+  }
+  // (u, v of the hit are in place already; without a hit nobody reads them)
   __device__ __forceinline__ void store(uint32_t i, const Hit &h, bool) const {
     hb.prim[i] = h.prim;
     hb.t[i] = h.t;
-    hb.u[i] = h.u;
-    hb.v[i] = h.v;
   }
 };
 
@@ -789,10 +908,10 @@ __global__ void TRAV_BOUNDS_N(PTAMD_WAVES_EXTEND)
     k_extend(DevScene S, RayQ q, const int32_t *__restrict__ list, HitBuf hb, Ctl *ctl, double min_t, double max_t,
              uint2 *gstack) {
   extern __shared__ uint2 lds_stack[];
-  const TravStack stack{lds_stack, gstack, gridDim.x * blockDim.x, blockIdx.x * blockDim.x + threadIdx.x, PTAMD_STACK_EXTEND};
+  const TravStack stack{(lds_uint2 *)lds_stack, gstack, gridDim.x * blockDim.x, blockIdx.x * blockDim.x + threadIdx.x, PTAMD_STACK_EXTEND};
   uint32_t cn = 0, ct = 0;
   const ExtendPolicy pol{q, list, hb, min_t, max_t};
-  trace_rays<false, COUNT, PTAMD_REFILL_EXTEND>(S, pol, ctl->n_cur, &ctl->grab[0], stack, cn, ct);
+  trace_rays<0, COUNT, PTAMD_REFILL_EXTEND>(S, pol, ctl->n_cur, &ctl->grab[0], stack, cn, ct);
   if (COUNT) {
     atomicAdd(&ctl->st_nodes, (unsigned long long)cn);
     atomicAdd(&ctl->st_tests, (unsigned long long)ct);
@@ -808,16 +927,23 @@ struct ShadowPolicy {
   ShadowQ sq;
   VertexBuf vb;
   uint32_t nls;
-  __device__ __forceinline__ bool load(uint32_t i, v3 &o, v3 &d, double &tmin, double &tmax) const {
+  float inv_nls;
+  __device__ __forceinline__ double min_t_all() const { return PT_EPS_D; }
+  __device__ __forceinline__ bool load(uint32_t i, v3 &o, v3 &d, double &tmax) const {
     const int32_t slot = sq.slot[i];
-    const uint32_t e = (uint32_t)slot / nls;
+    // slot / nls through a float quotient and one correction: the generic 32-bit division is
+    // a long instruction sequence that holds a dozen registers (slot < 2^31, nls < 2^16)
+    uint32_t e = (uint32_t)((float)slot * inv_nls);
+    const int32_t rem = slot - (int32_t)(e * nls);
+    e += rem >= (int32_t)nls ? 1u : 0u;
+    e -= rem < 0 ? 1u : 0u;
     o = V(vb.hp[0][e], vb.hp[1][e], vb.hp[2][e]);
     const SRay r = sq.ray[slot];
     d = V(r.d[0], r.d[1], r.d[2]);
-    tmin = PT_EPS_D;
     tmax = HEMI ? (double)INFINITY : r.max_t;
     return true;
   }
+  __device__ __forceinline__ void record(uint32_t, double, double) const {}
   __device__ __forceinline__ void store(uint32_t i, const Hit &h, bool found) const {
     const int32_t slot = sq.slot[i];
     if (!HEMI) {
@@ -842,11 +968,35 @@ template <bool HEMI, bool COUNT>
 __global__ void TRAV_BOUNDS_N(PTAMD_WAVES_SHADOW)
     k_shadow(DevScene S, ShadowQ sq, VertexBuf vb, Ctl *ctl, int32_t nls, uint2 *gstack) {
   extern __shared__ uint2 lds_stack[];
-  const TravStack stack{lds_stack, gstack, gridDim.x * blockDim.x, blockIdx.x * blockDim.x + threadIdx.x, PTAMD_STACK_SHADOW};
+  const TravStack stack{(lds_uint2 *)lds_stack, gstack, gridDim.x * blockDim.x, blockIdx.x * blockDim.x + threadIdx.x, PTAMD_STACK_SHADOW};
   uint32_t cn = 0, ct = 0;
-  const ShadowPolicy<HEMI> pol{S, sq, vb, (uint32_t)nls};
-  if (HEMI) trace_rays<false, COUNT, PTAMD_REFILL_SHADOW>(S, pol, ctl->n_shadow, &ctl->grab[1], stack, cn, ct);
-  else trace_rays<true, COUNT, PTAMD_REFILL_SHADOW>(S, pol, ctl->n_shadow, &ctl->grab[1], stack, cn, ct);
+  const ShadowPolicy<HEMI> pol{S, sq, vb, (uint32_t)nls, 1.0f / (float)nls};
+  if (HEMI) trace_rays<0, COUNT, PTAMD_REFILL_SHADOW>(S, pol, ctl->n_shadow, &ctl->grab[1], stack, cn, ct);
+  else trace_rays<1, COUNT, PTAMD_REFILL_SHADOW>(S, pol, ctl->n_shadow, &ctl->grab[1], stack, cn, ct);
+  if (COUNT) {
+    atomicAdd(&ctl->st_nodes, (unsigned long long)cn);
+    atomicAdd(&ctl->st_tests, (unsigned long long)ct);
+  }
+}
+
+// The bounce rays of the next depth (list and count: the queue k_scatter has just
+// written, Ctl::n_next) and the shadow rays of this depth, see trace_two_lists.
+template <bool HEMI, bool COUNT>
+__global__ void TRAV_BOUNDS_N(PTAMD_WAVES_EXTEND)
+    k_trace2(DevScene S, RayQ q, const int32_t *__restrict__ list, HitBuf hb, ShadowQ sq, VertexBuf vb, Ctl *ctl,
+             int32_t nls, uint2 *gstack) {
+  extern __shared__ uint2 lds_stack[];
+  const TravStack stack{(lds_uint2 *)lds_stack, gstack, gridDim.x * blockDim.x, blockIdx.x * blockDim.x + threadIdx.x, PTAMD_STACK_EXTEND};
+  uint32_t cn = 0, ct = 0;
+  const ExtendPolicy pe{q, list, hb, PT_EPS_D, (double)INFINITY};
+  for (int k = 0; k < 3; k++) vb.hp[k] = q.o[k];  // the same arrays (see ptamd_trace_list): one set of pointers to hold
+  const ShadowPolicy<HEMI> ps{S, sq, vb, (uint32_t)nls, 1.0f / (float)nls};
+  const uint32_t n_e = ctl->n_next, n_s = ctl->n_shadow;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {  // the only writer of these two during the launch
+    ctl->st_two_ext += n_e;
+    ctl->st_two_shadow += n_s;
+  }
+  trace_two_lists<HEMI, COUNT, PTAMD_REFILL_EXTEND>(S, pe, n_e, &ctl->grab[2], ps, n_s, &ctl->grab[1], stack, cn, ct);
   if (COUNT) {
     atomicAdd(&ctl->st_nodes, (unsigned long long)cn);
     atomicAdd(&ctl->st_tests, (unsigned long long)ct);
@@ -1435,6 +1585,7 @@ struct ptamd_context {
   ptamd_render_params params{};
   FrameParams fp{};
   // work buffers
+  bool trace_two = true;  // bounce rays of depth d + 1 and shadow rays of depth d in one launch (PTAMD_TRACE_TWO=0: apart)
   int64_t max_paths = 16 << 20;  // paths per launch: large launches amortise the drain of the slowest waves
   int64_t cap_paths = 0;
   int cap_nls = 0;
@@ -1454,6 +1605,7 @@ struct ptamd_context {
   size_t gstack_bytes = 0;
   // profiling
   bool prof_events = false, prof_counters = false;
+  uint32_t event_mask = 0xffffffffu;  // kernel classes whose launches are bracketed by events
   struct Ev { int cls; hipEvent_t a, b; };
   std::vector<Ev> events;
   std::vector<hipEvent_t> event_pool;  // recycled: creating an event per launch costs more than the launch
@@ -1496,9 +1648,11 @@ int light_samples_per_vertex(const ptamd_context *c, const ptamd_render_params *
 struct Launcher {
   ptamd_context *c;
   hipStream_t s;
+  bool timed = false;
   void begin(int cls) {
     c->stats.launches[cls]++;
-    if (c->prof_events) {
+    timed = c->prof_events && ((c->event_mask >> cls) & 1u);
+    if (timed) {
       ptamd_context::Ev e;
       e.cls = cls;
       e.a = c->take_event();
@@ -1508,7 +1662,7 @@ struct Launcher {
     }
   }
   void end() {
-    if (c->prof_events) (void)hipEventRecord(c->events.back().b, s);
+    if (timed) (void)hipEventRecord(c->events.back().b, s);
   }
 };
 
@@ -1643,6 +1797,7 @@ int ptamd_create(int32_t device_id, ptamd_context **out) {
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) c->num_cu = prop.multiProcessorCount;
   if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) c->own_stream = nullptr;
+  if (const char *e = getenv("PTAMD_TRACE_TWO")) c->trace_two = atoi(e) != 0;
   *out = c;
   return PTAMD_OK;
 }
@@ -1673,6 +1828,12 @@ int ptamd_set_profiling(ptamd_context *c, int32_t events, int32_t counters) {
   if (!c) { ptamd::set_error("null context"); return PTAMD_ERR_ARG; }
   c->prof_events = events != 0;
   c->prof_counters = counters != 0;
+  return PTAMD_OK;
+}
+
+int ptamd_set_event_classes(ptamd_context *c, uint32_t mask) {
+  if (!c) { ptamd::set_error("null context"); return PTAMD_ERR_ARG; }
+  c->event_mask = mask;
   return PTAMD_OK;
 }
 
@@ -2046,14 +2207,18 @@ int ptamd_trace_list(ptamd_context *c, const ptamd_pixel_list *list, int32_t sam
     hipLaunchKernelGGL(k_generate, ggrid, 256, 0, s, fp, c->S, pv, up0, c->ctl, rp, c->q[0], pb);
     L.end();
     int cur = 0;
+    bool traced_ahead = false;  // this depth's bounce rays went with the previous depth's shadow rays (k_trace2)
     for (int depth = 1; depth <= depths; depth++) {
       const double min_t = depth == 1 ? fp.n_clip : PT_EPS_D;
       const double max_t = depth == 1 ? fp.f_clip : (double)INFINITY;
       const int32_t *lst = depth == 1 ? nullptr : c->list[cur];
-      L.begin(PTAMD_K_EXTEND);
-      if (c->prof_counters) hipLaunchKernelGGL((k_extend<true>), egrid, tblock, elds, s, c->S, c->q[cur], lst, c->hb, c->ctl, min_t, max_t, gstack);
-      else hipLaunchKernelGGL((k_extend<false>), egrid, tblock, elds, s, c->S, c->q[cur], lst, c->hb, c->ctl, min_t, max_t, gstack);
-      L.end();
+      if (!traced_ahead) {
+        L.begin(PTAMD_K_EXTEND);
+        if (c->prof_counters) hipLaunchKernelGGL((k_extend<true>), egrid, tblock, elds, s, c->S, c->q[cur], lst, c->hb, c->ctl, min_t, max_t, gstack);
+        else hipLaunchKernelGGL((k_extend<false>), egrid, tblock, elds, s, c->S, c->q[cur], lst, c->hb, c->ctl, min_t, max_t, gstack);
+        L.end();
+      }
+      traced_ahead = false;
       VertexBuf vb = c->vb;
       for (int k = 0; k < 3; k++) vb.hp[k] = c->q[cur ^ 1].o[k];  // one copy of the hit point serves both uses
       L.begin(PTAMD_K_SHADE);
@@ -2069,15 +2234,28 @@ int ptamd_trace_list(ptamd_context *c, const ptamd_pixel_list *list, int32_t sam
       hipLaunchKernelGGL(k_scatter, ggrid, 256, 0, s, c->cp, vb, c->list[cur ^ 1], c->sq, c->ctl, fp.max_ray_depth > 0 ? fp.nls : 0);
       L.end();
       if (fp.max_ray_depth > 0 && fp.nls > 0) {
-        L.begin(PTAMD_K_SHADOW);
-        if (fp.hemisphere) {
-          if (c->prof_counters) hipLaunchKernelGGL((k_shadow<true, true>), sgrid, tblock, slds, s, c->S, c->sq, vb, c->ctl, nls, gstack);
-          else hipLaunchKernelGGL((k_shadow<true, false>), sgrid, tblock, slds, s, c->S, c->sq, vb, c->ctl, nls, gstack);
+        if (depth < depths && c->trace_two) {
+          // the next depth's bounce rays (queue cur ^ 1, just written) together with this depth's shadow rays;
+          // the hit records of this depth have been consumed by k_shade
+          L.begin(PTAMD_K_TRACE2);
+          const bool hemi = fp.hemisphere != 0, cnt = c->prof_counters;
+#define PTAMD_LAUNCH_TRACE2(H, C) hipLaunchKernelGGL((k_trace2<H, C>), egrid, tblock, elds, s, c->S, c->q[cur ^ 1], (const int32_t *)c->list[cur ^ 1], c->hb, c->sq, vb, c->ctl, nls, gstack)
+          if (hemi) { if (cnt) PTAMD_LAUNCH_TRACE2(true, true); else PTAMD_LAUNCH_TRACE2(true, false); }
+          else { if (cnt) PTAMD_LAUNCH_TRACE2(false, true); else PTAMD_LAUNCH_TRACE2(false, false); }
+#undef PTAMD_LAUNCH_TRACE2
+          L.end();
+          traced_ahead = true;
         } else {
-          if (c->prof_counters) hipLaunchKernelGGL((k_shadow<false, true>), sgrid, tblock, slds, s, c->S, c->sq, vb, c->ctl, nls, gstack);
-          else hipLaunchKernelGGL((k_shadow<false, false>), sgrid, tblock, slds, s, c->S, c->sq, vb, c->ctl, nls, gstack);
+          L.begin(PTAMD_K_SHADOW);
+          if (fp.hemisphere) {
+            if (c->prof_counters) hipLaunchKernelGGL((k_shadow<true, true>), sgrid, tblock, slds, s, c->S, c->sq, vb, c->ctl, nls, gstack);
+            else hipLaunchKernelGGL((k_shadow<true, false>), sgrid, tblock, slds, s, c->S, c->sq, vb, c->ctl, nls, gstack);
+          } else {
+            if (c->prof_counters) hipLaunchKernelGGL((k_shadow<false, true>), sgrid, tblock, slds, s, c->S, c->sq, vb, c->ctl, nls, gstack);
+            else hipLaunchKernelGGL((k_shadow<false, false>), sgrid, tblock, slds, s, c->S, c->sq, vb, c->ctl, nls, gstack);
+          }
+          L.end();
         }
-        L.end();
         L.begin(PTAMD_K_RESOLVE);
         hipLaunchKernelGGL(k_resolve, ggrid, 256, 0, s, fp, c->q[cur], lst, vb, pb, c->ctl, depth);
         hipLaunchKernelGGL(k_advance, 1, 1, 0, s, c->ctl);
@@ -2205,6 +2383,8 @@ int ptamd_get_stats(ptamd_context *c, ptamd_stats *out) {
     c->stats.nodes_visited = h.st_nodes;
     c->stats.prim_tests = h.st_tests;
     c->stats.samples = h.st_samples;
+    c->stats.two_ext_rays = h.st_two_ext;
+    c->stats.two_shadow_rays = h.st_two_shadow;
   }
   *out = c->stats;
   return PTAMD_OK;

@@ -31,4 +31,4 @@ print("stride %d per_pixel %d target %d max_batches %d lag %d: frame %.2f ms, %d
 print(" bounds:", [b for _, b, _ in rounds])
 print(" samples kept %d, rays %d (%.2f per kept sample), shadow %d, launches %d" % (
     st.samples, st.rays, st.rays / max(st.samples, 1), st.shadow_rays, sum(st.launches)))
-print(" kernel ms:", {cabi.K_NAMES[k]: round(st.kernel_ms[k], 2) for k in range(8)})
+print(" kernel ms:", {cabi.K_NAMES[k]: round(st.kernel_ms[k], 2) for k in range(12) if st.launches[k]})

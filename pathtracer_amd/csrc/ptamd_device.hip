@@ -528,7 +528,10 @@ struct Walk {
 //    slower than the grid-stride one. Hence closest-hit walks run at 5 waves per
 //    SIMD (no spills) and any-hit walks, which carry less state, at 6.
 //
-// Also measured and rejected: sorting each workgroup's 256 rays by direction
+// Also measured and rejected: claims that shrink towards the end of the list (guided
+// self-scheduling, so that no wave holds unstarted rays while others idle): 7 % slower, a
+// claim stalls the whole wave for an atomic's round trip and the end of a launch is bound by
+// its longest walks, not by imbalance; sorting each workgroup's 256 rays by direction
 // octant (no gain); one box step or one primitive test per trip (if / else),
 // or box steps until every lane has a primitive (while-while): 5 % and 25 %
 // slower; cutting the list into one contiguous band per XCD so that each XCD's
@@ -1431,6 +1434,9 @@ __device__ __forceinline__ bool pixel_continues(const double *st, int32_t i, dou
 // already computed. A round may hold several batches of a pixel, traced ahead of
 // their adaptive tests; the test runs here between the batches, and what was
 // traced past a pixel's stop is dropped. state: [pixel*6] = s1, s2, sum.rgb, n.
+// (One thread per pixel: its loads are not coalesced, but a wave per pixel with coalesced
+// loads and the ordered sum passed lane to lane was measured 2.5 times slower; the serial
+// additions, not the loads, are what a pixel costs.)
 __global__ void k_accumulate(PixView pv, uint32_t p0, Ctl *ctl, RoundPlan rp, PathBuf pb, double *__restrict__ state) {
   const uint32_t stride = gridDim.x * blockDim.x;
   const uint32_t n_pixels = ctl->n_pix;

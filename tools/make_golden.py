@@ -121,15 +121,21 @@ def blocks(img, b=8):
     return v if img.ndim == 3 else v[..., 0]
 
 
-def block_goldens():
-    """BASELINE.json's configurations 1 and 2 rendered by the reference at full size; kept as
+def block_goldens(only=None):
+    """BASELINE.json's configurations 1 to 3 rendered by the reference at full size (3: the
+    stand-in for the absent CBdragon.dae, written by tools/make_standin_scene.py); kept as
     8x8 block means (they keep any bias and little noise) so the fixtures stay small."""
-    sc = scenes()
+    import make_standin_scene
+    sc = dict(scenes())
+    sc["CBdragon_standin"] = make_standin_scene.ensure("dragon")
     jobs = [
+        ("config3_dragon_standin_800x600_s1024_l4_m5", "CBdragon_standin", ["-s", "1024", "-l", "4", "-m", "5", "-r", "800", "600"], 800, 600),
         ("config1_cbsl_480x360_s64_l16_m5", "CBspheres_lambertian", ["-s", "64", "-l", "16", "-m", "5", "-r", "480", "360"], 480, 360),
         ("config2_cbbunny_800x600_s256_l4_m5", "CBbunny", ["-s", "256", "-l", "4", "-m", "5", "-r", "800", "600"], 800, 600),
     ]
     for tag, name, args, w, h in jobs:
+        if only and only not in tag:
+            continue
         out = os.path.join(TMP, "b.ptar")
         t0 = time.time()
         run(["render"] + args + ["-t", "8", "-f", out, sc[name]])
@@ -148,7 +154,7 @@ if __name__ == "__main__":
         raise SystemExit("build the reference driver first: make -C oracle ref")
     if len(sys.argv) > 1 and sys.argv[1] == "blocks":
         os.makedirs(TMP, exist_ok=True)
-        block_goldens()
+        block_goldens(sys.argv[2] if len(sys.argv) > 2 else None)
     else:
         main()
         block_goldens()

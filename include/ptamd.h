@@ -239,12 +239,24 @@ typedef struct ptamd_pixel_list {
  * pathtracer.cpp:250-258 is then applied between the batches while the samples
  * are summed, and samples traced past a pixel's stop are dropped, so the state
  * is what one call per batch with a filter in between would have left. Tracing
- * ahead like this is how small rounds are kept from leaving the GPU idle. */
+ * ahead like this is how small rounds are kept from leaving the GPU idle.
+ *
+ * sample_base = -1 (n_samples then a multiple of samples_per_batch): every pixel
+ * goes on from its OWN count (state n) and is traced ahead by as many batches, at
+ * most n_samples / samples_per_batch, as its running mean and variance predict
+ * it still needs before the adaptive test passes; the state is again what the
+ * reference's per-pixel loop would have left, only the moment a sample is traced
+ * changes. Pair it with ptamd_filter_list(n_done = -1).
+ *
+ * A frame's calls must reach the device in order (one stream, or streams the
+ * caller orders); ptamd_frame_begin itself touches no device memory. */
 int ptamd_trace_list(ptamd_context *ctx, const ptamd_pixel_list *list, int32_t sample_base,
                      int32_t n_samples, double *d_state, void *stream);
 /* ptamd_adaptive_filter for such a list (offset 0, stride 1). A pixel survives if
  * it used all n_done samples traced for it so far (it did not stop at a test
- * inside an earlier multi-batch round) and the test at i = n_done lets it go on. */
+ * inside an earlier multi-batch round) and the test at i = n_done lets it go on.
+ * n_done = -1: every pixel is judged at its own count, as raytrace_pixel's loop
+ * would (done at ns_aa samples, tested at every positive multiple of the batch). */
 int ptamd_filter_list(ptamd_context *ctx, const ptamd_pixel_list *in, int32_t n_done, const double *d_state,
                       int32_t *d_pixels_out, int64_t *d_n_out, void *stream);
 /* The exchange after a round, the counterpart of the reference's shared

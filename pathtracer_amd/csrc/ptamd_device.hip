@@ -1591,6 +1591,7 @@ struct ptamd_context {
   ptamd_render_params params{};
   FrameParams fp{};
   // work buffers
+  bool clear_ctl = false;  // the next ptamd_trace_list zeroes the device-side counters first
   bool trace_two = true;  // bounce rays of depth d + 1 and shadow rays of depth d in one launch (PTAMD_TRACE_TWO=0: apart)
   int64_t max_paths = 16 << 20;  // paths per launch: large launches amortise the drain of the slowest waves
   int64_t cap_paths = 0;
@@ -2118,7 +2119,10 @@ int ptamd_frame_begin(ptamd_context *c, const ptamd_render_params *p) {
     collect_events(c);  // timings of earlier frames are not part of this one
   }
   memset(&c->stats, 0, sizeof c->stats);
-  if (c->ctl) HIPCHK(hipMemset(c->ctl, 0, sizeof(Ctl)));
+  // The device-side counters are cleared by the frame's first ptamd_trace_list, on ITS stream: a
+  // memset issued here, on the null stream, would not be ordered against an earlier frame still
+  // running on a non-blocking stream.
+  c->clear_ctl = true;
   return PTAMD_OK;
 }
 
@@ -2193,6 +2197,10 @@ int ptamd_trace_list(ptamd_context *c, const ptamd_pixel_list *list, int32_t sam
   TravLaunch tl;
   rc = traversal_launch(c, &tl);
   if (rc) return rc;
+  if (c->clear_ctl) {
+    HIPCHK(hipMemsetAsync(c->ctl, 0, sizeof(Ctl), s));
+    c->clear_ctl = false;
+  }
   const int tblock = tl.block;
   const int egrid = tl.grid_extend, sgrid = tl.grid_shadow;
   const size_t elds = tl.lds_extend, slds = tl.lds_shadow;

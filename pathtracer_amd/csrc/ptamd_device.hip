@@ -125,17 +125,16 @@ struct HitBuf {
   int32_t *prim;
   double *t, *u, *v;
 };
-// Per light sample (slot = entry * nls + q) the records are arrays of 32-byte
-// structures: the nls samples of one vertex are written by one lane of k_shade as
-// one contiguous run, and a shadow ray or a resolve reads its record with two
-// 16-byte loads.
+// Per light sample (slot = entry * nls + q) the records are arrays of structures
+// (shadow ray 32 bytes, contribution 24): the nls samples of one vertex are written by
+// one lane of k_shade as one contiguous run, and a shadow ray reads its record with
+// two 16-byte loads.
 struct alignas(32) SRay {
   double d[3];
   double max_t;  // hemisphere mode: cos term instead
 };
-struct alignas(32) Contrib {
+struct Contrib {  // 24 bytes: the kernels that touch it are bound by the bytes they move
   double c[3];
-  double pad;
 };
 struct ShadowQ {
   int32_t *slot;  // entry * nls + q
@@ -960,7 +959,7 @@ struct ShadowPolicy {
         const Contrib cf = vb.contrib[slot];
         const v3 f = V(cf.c[0], cf.c[1], cf.c[2]);
         const v3 term = vscale(vscale(vscale(vmul(f, light_L), sq.ray[slot].max_t), 2), PT_PI);
-        vb.contrib[slot] = Contrib{{term.x, term.y, term.z}, 0.0};
+        vb.contrib[slot] = Contrib{{term.x, term.y, term.z}};
       }
       vb.vis[slot] = found ? 1 : 0;
     }
@@ -1234,7 +1233,7 @@ __global__ void __launch_bounds__(256)
             if (!(wi_o.z < 0 || (radiance.x == 0 && radiance.y == 0 && radiance.z == 0))) {
               const v3 term = vdivs(vscale(vmul(f, radiance), fabs(wi_o.z)), pdf);
               sq.ray[slot] = SRay{{wi.x, wi.y, wi.z}, dist};
-              vb.contrib[slot] = Contrib{{term.x, term.y, term.z}, 0.0};
+              vb.contrib[slot] = Contrib{{term.x, term.y, term.z}};
               vis.put(slot, 2);
               n_emit++;
             } else {
@@ -1251,7 +1250,7 @@ __global__ void __launch_bounds__(256)
           const double cs = vdot(wi, mmul(w2o, n_sh));
           const size_t slot = (size_t)i * nls + qq;
           sq.ray[slot] = SRay{{wd3.x, wd3.y, wd3.z}, cs};
-          vb.contrib[slot] = Contrib{{f.x, f.y, f.z}, 0.0};
+          vb.contrib[slot] = Contrib{{f.x, f.y, f.z}};
           vis.put(slot, 2);
           n_emit++;
         }
@@ -1277,31 +1276,47 @@ __global__ void __launch_bounds__(256)
 // Exclusive scan of the two per-block count arrays (one workgroup); the totals
 // become the sizes of the next ray list and of the shadow-ray list.
 __global__ void __launch_bounds__(1024) k_scan2(Compact cp, Ctl *ctl) {
-  __shared__ uint32_t tmp[2][1024];
+  // per pass: 8 counts per thread summed serially, a shuffle scan inside each wave, the 16 wave
+  // totals through LDS (three barriers per 8192 counts)
+  __shared__ uint32_t wtot[2][16];
   __shared__ uint32_t carry[2];
+  constexpr int IT = 8;
   const uint32_t n_blocks = (ctl->n_cur + 255u) >> 8;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   if (threadIdx.x < 2) carry[threadIdx.x] = 0;
   __syncthreads();
-  for (uint32_t base = 0; base < n_blocks; base += 1024) {
-    const uint32_t i = base + threadIdx.x;
-    const uint32_t a = i < n_blocks ? cp.cnt_next[i] : 0, b = i < n_blocks ? cp.cnt_shadow[i] : 0;
-    tmp[0][threadIdx.x] = a;
-    tmp[1][threadIdx.x] = b;
-    __syncthreads();
-    for (uint32_t off = 1; off < 1024; off <<= 1) {
-      const uint32_t x = threadIdx.x >= off ? tmp[0][threadIdx.x - off] : 0;
-      const uint32_t y = threadIdx.x >= off ? tmp[1][threadIdx.x - off] : 0;
-      __syncthreads();
-      tmp[0][threadIdx.x] += x;
-      tmp[1][threadIdx.x] += y;
-      __syncthreads();
+  for (uint32_t base = 0; base < n_blocks; base += 1024 * IT) {
+    const uint32_t i0 = base + threadIdx.x * IT;
+    uint32_t a[IT], b[IT], sa = 0, sb = 0;
+#pragma unroll
+    for (int k = 0; k < IT; k++) {
+      const bool in = i0 + k < n_blocks;
+      a[k] = in ? cp.cnt_next[i0 + k] : 0u;
+      b[k] = in ? cp.cnt_shadow[i0 + k] : 0u;
+      sa += a[k];
+      sb += b[k];
     }
-    if (i < n_blocks) {
-      cp.cnt_next[i] = carry[0] + tmp[0][threadIdx.x] - a;
-      cp.cnt_shadow[i] = carry[1] + tmp[1][threadIdx.x] - b;
+    uint32_t xa = sa, xb = sb;  // inclusive scan over the wave's threads
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t ua = __shfl_up(xa, off), ub = __shfl_up(xb, off);
+      if (lane >= off) { xa += ua; xb += ub; }
+    }
+    if (lane == 63) { wtot[0][wv] = xa; wtot[1][wv] = xb; }
+    __syncthreads();
+    uint32_t pa = carry[0], pb = carry[1];
+    for (int k = 0; k < wv; k++) { pa += wtot[0][k]; pb += wtot[1][k]; }
+    uint32_t ea = pa + xa - sa, eb = pb + xb - sb;  // exclusive prefix of this thread's first count
+#pragma unroll
+    for (int k = 0; k < IT; k++) {
+      if (i0 + k < n_blocks) {
+        cp.cnt_next[i0 + k] = ea;
+        cp.cnt_shadow[i0 + k] = eb;
+      }
+      ea += a[k];
+      eb += b[k];
     }
     __syncthreads();
-    if (threadIdx.x == 1023) { carry[0] += tmp[0][1023]; carry[1] += tmp[1][1023]; }
+    if (threadIdx.x == 1023) { carry[0] = pa + xa; carry[1] = pb + xb; }
     __syncthreads();
   }
   if (threadIdx.x == 0) {

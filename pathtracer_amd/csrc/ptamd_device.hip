@@ -539,6 +539,46 @@ struct Walk {
 #ifndef PTAMD_GRAB
 #define PTAMD_GRAB 256
 #endif
+// How a persistent wave gets rays from a list of n. Its FIRST chunk is fixed: wave w owns
+// [w g, (w + 1) g). Only what lies beyond waves x g is handed out through the shared counter.
+// Thousands of waves adding to one address are served one after the other (~20 ns each): with
+// every wave's first claim going through the counter a launch of 64 rays took 105 us (now 52),
+// and every launch began with such a queue.
+struct Claims {
+  uint32_t n, g, dyn0;  // list length, chunk size, first ray handed out through the counter
+  uint32_t *counter;
+  // own_chunks = false: everything goes through the counter (a list the waves reach one by one, when
+  // they run out of another: a wave held up by long walks would sit on its own chunk)
+  __device__ __forceinline__ void init(uint32_t n_, uint32_t *counter_, uint32_t waves, bool own_chunks) {
+    n = n_;
+    counter = counter_;
+    const uint32_t per_wave = n / waves;
+    // PTAMD_GRAB, less when the list is too short to give every wave that many
+    g = per_wave >= PTAMD_GRAB ? PTAMD_GRAB : (per_wave < 64u ? 64u : (per_wave & ~63u));
+    dyn0 = own_chunks ? waves * g : 0u;
+  }
+  // the wave's own first chunk; false if the list ends before it
+  __device__ __forceinline__ bool first(uint32_t wave, uint32_t &next, uint32_t &end) const {
+    next = wave * g;
+    end = next + g < n ? next + g : n;
+    return next < n;
+  }
+  // A further chunk; false when the list is handed out. Call with all lanes active; the result is
+  // wave-uniform and lives in scalar registers. (Looking at the counter with a plain load before
+  // adding to it, to spare the adds that come back empty at the end of a list, was measured: the
+  // loads queue up behind the adds on the same line, +6 % frame time.)
+  __device__ __forceinline__ bool more(int lane, uint32_t &next, uint32_t &end) const {
+    if (dyn0 >= n) return false;  // the waves' own chunks cover the whole list
+    uint32_t base = 0;
+    if (lane == 0) base = dyn0 + atomicAdd(counter, g);
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    if (base >= n) return false;
+    next = base;
+    end = base + g < n ? base + g : n;
+    return true;
+  }
+};
+
 template <int ANY, bool COUNT, int REFILL, class Policy>
 __device__ __forceinline__ void trace_rays(const DevScene &S, const Policy &pol, uint32_t n, uint32_t *grab,
                                            const TravStack &stack, uint32_t &n_nodes, uint32_t &n_tests) {
@@ -564,27 +604,21 @@ __device__ __forceinline__ void trace_rays(const DevScene &S, const Policy &pol,
     }
     return;
   }
-  // rays claimed at a time: PTAMD_GRAB, less when the list is too short to give every wave that many
-  const uint32_t per_wave = n / (gridDim.x * (TRAV_BLOCK / 64u));
-  const uint32_t GRAB = per_wave >= PTAMD_GRAB ? PTAMD_GRAB : (per_wave < 64u ? 64u : (per_wave & ~63u));
   const int lane = threadIdx.x & 63;
   const unsigned long long below = (1ull << lane) - 1ull;
+  Claims cl;
+  cl.init(n, grab, gridDim.x * (TRAV_BLOCK / 64u), true);
   uint32_t next = 0, end = 0, idx = 0;
   bool exhausted = false, active = false;
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (TRAV_BLOCK / 64u) + (threadIdx.x >> 6)));
+  if (!cl.first(wave, next, end)) { exhausted = true; next = end = 0; }
   w.cur = CHILD_EMPTY;
   w.sp = 0;
   for (;;) {
     const unsigned long long idle = __ballot(!active);
     const int n_idle = __popcll(idle);
     if (n_idle >= REFILL && !exhausted) {
-      if (next >= end) {
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(grab, GRAB);
-        base = (uint32_t)__shfl((int)base, 0);
-        next = base;
-        end = base + GRAB < n ? base + GRAB : n;
-        if (base >= n) { exhausted = true; next = end = 0; }
-      }
+      if (next >= end && !cl.more(lane, next, end)) { exhausted = true; next = end = 0; }
       if (next < end) {
         // idle lanes take the next rays in lane order
         const uint32_t mine = next + (uint32_t)__popcll(idle & below);
@@ -636,13 +670,14 @@ __device__ __forceinline__ void trace_two_lists(const DevScene &S, const PolE &p
   const double min_t = pe.min_t_all();  // == ps.min_t_all(): both kinds of ray leave a surface
   const float m0 = fmaxf(f_down(min_t), 0.f);
   const uint32_t waves = gridDim.x * (TRAV_BLOCK / 64u);
-  const uint32_t pw_e = n_e / waves, pw_s = n_s / waves;
-  const uint32_t g_e = pw_e >= PTAMD_GRAB ? PTAMD_GRAB : (pw_e < 64u ? 64u : (pw_e & ~63u));
-  const uint32_t g_s = pw_s >= PTAMD_GRAB ? PTAMD_GRAB : (pw_s < 64u ? 64u : (pw_s & ~63u));
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (TRAV_BLOCK / 64u) + (threadIdx.x >> 6)));
   const int lane = threadIdx.x & 63;
   const unsigned long long below = (1ull << lane) - 1ull;
+  Claims cl;  // of the list being claimed
+  cl.init(n_e, grab_e, waves, true);
   uint32_t next = 0, end = 0, idx = 0;
   int phase = 0;  // list being claimed: 0 = E, 1 = S, 2 = both are handed out (wave-uniform)
+  bool own_chunk = true;  // the wave has yet to take its own first chunk of the list of `phase`
   bool active = false, from_s = false;
   w.cur = CHILD_EMPTY;
   w.sp = 0;
@@ -651,22 +686,14 @@ __device__ __forceinline__ void trace_two_lists(const DevScene &S, const PolE &p
     const int n_idle = __popcll(idle);
     if (n_idle >= REFILL && phase < 2) {
       if (next >= end) {
-        uint32_t base = 0, n, g;
-        if (phase == 0) {
-          n = n_e; g = g_e;
-          if (lane == 0) base = atomicAdd(grab_e, g_e);
-        } else {
-          n = n_s; g = g_s;
-          if (lane == 0) base = atomicAdd(grab_s, g_s);
-        }
-        base = (uint32_t)__shfl((int)base, 0);
-        if (base >= n) {  // this list is handed out: on to the next one
+        const bool got = own_chunk ? cl.first(wave, next, end) : cl.more(lane, next, end);
+        own_chunk = false;
+        if (!got) {  // this list is handed out: on to the next one
           phase++;
+          cl.init(n_s, grab_s, waves, false);
           next = end = 0;
           continue;
         }
-        next = base;
-        end = base + g < n ? base + g : n;
       }
       const uint32_t mine = next + (uint32_t)__popcll(idle & below);
       if (!active && mine < end) {

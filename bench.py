@@ -54,7 +54,8 @@ def parse_args():
     ap.add_argument("--target-paths", type=int, default=16 << 20, help="see PixelSchedule.batches")
     ap.add_argument("--max-batches", type=int, default=32)
     ap.add_argument("--per-pixel", type=int, default=0,
-                    help="1: pixels are traced ahead only as far as their statistics predict (see render_frame)")
+                    help="1: pixels are traced ahead only as far as their statistics predict (see render_frame); "
+                         "0: all pixels of a round in lockstep")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL; the real thing) or gloo (rehearsal of the "
                     "multi-rank flow with several ranks on one GPU, rows staged through the host)")
     ap.add_argument("--pixel-stride", type=int, default=1,
@@ -273,7 +274,8 @@ def main():
                 dev.set_profiling(events=False, counters=True)
                 pc = cabi.make_params(args.width, args.height, ns_aa=min(spp, 64), max_ray_depth=args.depth,
                                       ns_area_light=args.light_samples, seed=77, specular=args.specular)
-                distributed.render_frame(dev, pc, device=device, pixel_stride=args.pixel_stride)
+                distributed.render_frame(dev, pc, device=device, pixel_stride=args.pixel_stride,
+                                         per_pixel=bool(args.per_pixel))
                 sc_ = dev.stats()
                 if sc_.rays:
                     own = {"nodes_per_ray": sc_.nodes_visited / 4.0 / sc_.rays, "prims_per_ray": sc_.prim_tests / sc_.rays}

@@ -70,7 +70,7 @@ class PixelSchedule:
 
 
 def render_frame(dev, params, rank=0, world=1, group=None, device=None, record_rounds=None, lag=1,
-                 pixel_stride=1, target_paths=16 << 20, max_batches=32, per_pixel=False):
+                 pixel_stride=1, target_paths=16 << 20, max_batches=32, per_pixel=False, sync_below=None):
     """Renders one frame; returns (hdr[h,w,3], count[h,w]) as tensors on `device`, on every rank.
 
     dev: api.Device with scene and camera set. With world > 1 the default process
@@ -85,6 +85,9 @@ def render_frame(dev, params, rank=0, world=1, group=None, device=None, record_r
     the same on every rank (it is a count, not a timing), so the ranks' collectives
     always agree in size. record_rounds, if a list, receives (samples_done,
     bound, this rank's share of the bound) per round.
+
+    sync_below: bounds at or below this many pixels are not lagged (see the loop). Default: 16384
+    with per_pixel (whose loop ends only when the list is seen to be empty), 0 otherwise.
 
     target_paths, max_batches: see PixelSchedule.batches (max_batches = 1 keeps to
     one batch per round, the reference's own cadence).
@@ -122,6 +125,8 @@ def render_frame(dev, params, rank=0, world=1, group=None, device=None, record_r
     dev.frame_begin(params)
     cur, done, bound = 0, 0, n0
     batch = params.samples_per_batch
+    if sync_below is None:
+        sync_below = 16384 if per_pixel else 0
     # per_pixel: `done` is the least count any listed pixel can have (a pixel gains at
     # least one batch per round), which bounds the number of rounds
     while done < params.ns_aa and bound > 0:
@@ -139,7 +144,9 @@ def render_frame(dev, params, rank=0, world=1, group=None, device=None, record_r
                 ev = torch.cuda.Event()
                 ev.record(torch.cuda.current_stream(device))
             pending.append((ev, host_n))
-            while len(pending) > lag:
+            # (a short list is read back at once: waiting for its count idles the GPU for tens of
+            # microseconds, queueing a round for pixels that have all stopped costs a round of launches)
+            while len(pending) > (lag if bound > sync_below else 0):
                 ev, t = pending.pop(0)
                 if ev is not None:
                     ev.synchronize()

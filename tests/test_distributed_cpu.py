@@ -155,7 +155,8 @@ def _worker_body(rank, world, port, q):
     traced = dev.traced
     # the pipelined schedule (bounds one round old) must give the same frame, and so
     # must rounds that trace several batches ahead of their adaptive tests
-    for kw in (dict(lag=1, max_batches=1), dict(lag=1), dict(lag=0, max_batches=2), dict(lag=1, per_pixel=True),
+    for kw in (dict(lag=1, max_batches=1, sync_below=0), dict(lag=1), dict(lag=0, max_batches=2),
+               dict(lag=1, per_pixel=True, sync_below=0), dict(lag=1, per_pixel=True),
                dict(lag=0, max_batches=2, per_pixel=True)):
         hdr_l, cnt_l = distributed.render_frame(dev, p, rank=rank, world=world, device=cpu, **kw)
         assert torch.equal(hdr_l, hdr) and torch.equal(cnt_l, cnt), "%r: frame differs" % (kw,)
@@ -183,7 +184,7 @@ def test_two_ranks_equal_one_rank_bit_for_bit():
     hdr1, cnt1 = hdr1.numpy(), cnt1.numpy()
     rounds_l = []
     hdr_l, cnt_l = distributed.render_frame(one, p, device=torch.device("cpu"), record_rounds=rounds_l, lag=1,
-                                            max_batches=1)
+                                            max_batches=1, sync_below=0)  # (every bound lagged, however short the list)
     assert np.array_equal(hdr_l.numpy(), hdr1) and np.array_equal(cnt_l.numpy(), cnt1)
     # several batches per round, traced ahead of the adaptive tests: same frame, fewer rounds
     rounds_s = []

@@ -38,10 +38,11 @@ def test_render_frame_pipelined_equals_synchronous_equals_render(device):
     hdr_r, cnt_r = device.render(p)
     assert np.array_equal(hdr_r, hdr_b) and np.array_equal(cnt_r, cnt_b)
     assert device.stats().samples == int(cnt_b.sum()), "only the samples that were kept count"
-    for kw in (dict(lag=1, max_batches=1), dict(lag=2, max_batches=1), dict(lag=1), dict(lag=0, max_batches=2),
+    for kw in (dict(lag=1, max_batches=1, sync_below=0), dict(lag=2, max_batches=1, sync_below=0), dict(lag=1),
+               dict(lag=0, max_batches=2),
                dict(lag=1, max_batches=4, target_paths=200000),
                # every pixel from its own count, traced ahead as far as its statistics predict
-               dict(lag=1, per_pixel=True), dict(lag=0, max_batches=2, per_pixel=True),
+               dict(lag=1, per_pixel=True, sync_below=0), dict(lag=0, max_batches=2, per_pixel=True),
                dict(lag=2, max_batches=6, target_paths=400000, per_pixel=True)):
         rounds = []
         hdr, cnt = distributed.render_frame(device, p, device=cuda, record_rounds=rounds, **kw)

@@ -815,6 +815,21 @@ __device__ __forceinline__ v3 light_sample_L(const DevScene &S, int li, v3 p, do
 }
 
 // ------------------------------------------------------------------ kernels
+// Adds the workgroup's sum of v to *dst with ONE atomic (every thread of the workgroup must call
+// it): adds to one address are served one after the other, ~20 ns each, and a launch does not end
+// before its last one, so an add per wave of a 2048-workgroup launch is a 0.16 ms tail.
+__device__ __forceinline__ void block_add(unsigned long long *dst, unsigned long long v) {
+  __shared__ unsigned long long part[16];
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long t = 0;
+    for (int k = 0; k < (int)((blockDim.x + 63) >> 6); k++) t += part[k];
+    if (t) atomicAdd(dst, t);
+  }
+}
+
 // Start of a chunk: pixels [p0, p0 + chunk) of the shard, ns paths each.
 __global__ void k_set_counts(Ctl *ctl, PixView pv, uint32_t p0, uint32_t chunk, uint32_t ns) {
   const uint32_t have = pv.count();
@@ -881,8 +896,7 @@ __global__ void k_generate(FrameParams fp, DevScene S, PixView pv, uint32_t p0, 
     q.o[0][k] = o.x; q.o[1][k] = o.y; q.o[2][k] = o.z;
     q.d[0][k] = d.x; q.d[1][k] = d.y; q.d[2][k] = d.z;
   }
-  for (int off = 32; off > 0; off >>= 1) dead += __shfl_down(dead, off);
-  if ((threadIdx.x & 63) == 0 && dead) atomicAdd(&ctl->st_dead, dead);
+  block_add(&ctl->st_dead, dead);
 }
 
 // camera rays through caller-given sensor positions (ptamd_trace_primary)
@@ -1440,9 +1454,7 @@ __global__ void k_resolve(FrameParams fp, RayQ q, const int32_t *__restrict__ li
       }
     }
   }
-  // one add per wave
-  for (int off = 32; off > 0; off >>= 1) verts += __shfl_down(verts, off);
-  if ((threadIdx.x & 63) == 0 && verts) atomicAdd(&ctl->st_vertices, verts);
+  block_add(&ctl->st_vertices, verts);
 }
 
 // Vector3D::illum (CGL/include/CGL/vector3D.h:231-233): double arithmetic, float result
@@ -1504,8 +1516,7 @@ __global__ void k_accumulate(PixView pv, uint32_t p0, Ctl *ctl, RoundPlan rp, Pa
     st[5] += (double)s;
     kept += (unsigned long long)s;
   }
-  for (int off = 32; off > 0; off >>= 1) kept += __shfl_down(kept, off);
-  if ((threadIdx.x & 63) == 0 && kept) atomicAdd(&ctl->st_samples, kept);
+  block_add(&ctl->st_samples, kept);
 }
 
 // Ordered stream compaction of the still-active pixels, three small kernels:

@@ -1502,15 +1502,36 @@ __global__ void k_accumulate(PixView pv, uint32_t p0, Ctl *ctl, RoundPlan rp, Pa
     double acc[2] = {st[0], st[1]};
     v3 sum = V(st[2], st[3], st[4]);
     const size_t b = (size_t)p * (uint32_t)rp.ns;
+    // runs of samples between two tests: inside a run nothing depends on the sums, so its loads
+    // are issued eight at a time; the additions stay in sample order
     int s = 0;
-    for (; s < planned; s++) {
-      const int i = first + s;
-      if (s > 0 && i % rp.batch == 0 && !pixel_continues(acc, i, rp.tol)) break;
-      const v3 L = V(pb.rad[0][b + s], pb.rad[1][b + s], pb.rad[2][b + s]);
-      const double xl = illum(L);
-      acc[0] += xl;
-      acc[1] += xl * xl;
-      sum = vadd(sum, L);
+    int next_test = (first / rp.batch + 1) * rp.batch;  // the test comes before sample i = next_test
+    while (s < planned) {
+      if (s > 0 && first + s == next_test) {
+        if (!pixel_continues(acc, next_test, rp.tol)) break;
+        next_test += rp.batch;
+      }
+      const int run_end = next_test - first < planned ? next_test - first : planned;
+      for (; s + 8 <= run_end; s += 8) {
+        double Lx[8], Ly[8], Lz[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) { Lx[k] = pb.rad[0][b + s + k]; Ly[k] = pb.rad[1][b + s + k]; Lz[k] = pb.rad[2][b + s + k]; }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          const v3 L = V(Lx[k], Ly[k], Lz[k]);
+          const double xl = illum(L);
+          acc[0] += xl;
+          acc[1] += xl * xl;
+          sum = vadd(sum, L);
+        }
+      }
+      for (; s < run_end; s++) {
+        const v3 L = V(pb.rad[0][b + s], pb.rad[1][b + s], pb.rad[2][b + s]);
+        const double xl = illum(L);
+        acc[0] += xl;
+        acc[1] += xl * xl;
+        sum = vadd(sum, L);
+      }
     }
     st[0] = acc[0]; st[1] = acc[1]; st[2] = sum.x; st[3] = sum.y; st[4] = sum.z;
     st[5] += (double)s;

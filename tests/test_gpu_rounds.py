@@ -124,3 +124,58 @@ def test_list_argument_errors(device):
         device.unpack_rows(cabi.PixelList(buf.data_ptr(), 0, 16, 16, 1, 2), 2, 0, state.data_ptr(), 8, state.data_ptr())
     # an empty shard is not an error
     device.trace_list(cabi.PixelList(buf.data_ptr(), 0, 1, 1, 3, 4), 0, 4, state.data_ptr())
+
+
+def test_fused_and_separate_traversal_launches_give_the_same_frame(device, monkeypatch):
+    """k_trace2 (bounce rays of depth d + 1 and shadow rays of depth d in one launch) against one
+    launch per kind (PTAMD_TRACE_TWO=0, read when a context is created): which lane traces a ray,
+    and in which launch, must not show in the result."""
+    p = cabi.make_params(W, H, ns_aa=64, max_ray_depth=5, ns_area_light=4, seed=11)
+    sc = pt.Scene(scene_path("CBbunny"))
+    device.upload(sc)
+    device.set_camera(sc.camera(W, H))
+    hdr_f, cnt_f = device.render(p)
+    st_f = device.stats()
+    assert st_f.launches[cabi.K_TRACE2] > 0 and st_f.two_ext_rays > 0 and st_f.two_shadow_rays > 0
+    monkeypatch.setenv("PTAMD_TRACE_TWO", "0")
+    other = pt.Device(0)
+    try:
+        other.upload(sc)
+        other.set_camera(sc.camera(W, H))
+        hdr_s, cnt_s = other.render(p)
+        st_s = other.stats()
+    finally:
+        other.close()
+    assert st_s.launches[cabi.K_TRACE2] == 0 and st_s.two_ext_rays == 0
+    assert np.array_equal(cnt_f, cnt_s) and np.array_equal(hdr_f, hdr_s)
+    assert (st_f.rays, st_f.shadow_rays, st_f.samples) == (st_s.rays, st_s.shadow_rays, st_s.samples)
+    # hemisphere lighting: the second list's rays are closest-hit walks too
+    ph = cabi.make_params(W, H, ns_aa=32, max_ray_depth=3, ns_area_light=2, seed=3, hemisphere=True)
+    hdr_f, cnt_f = device.render(ph)
+    monkeypatch.setenv("PTAMD_TRACE_TWO", "0")
+    other = pt.Device(0)
+    try:
+        other.upload(sc)
+        other.set_camera(sc.camera(W, H))
+        hdr_s, cnt_s = other.render(ph)
+    finally:
+        other.close()
+    assert np.array_equal(cnt_f, cnt_s) and np.array_equal(hdr_f, hdr_s)
+
+
+def test_event_classes_restrict_what_is_timed(device):
+    p = _setup(device)
+    device.set_profiling(events=True, counters=False)
+    try:
+        device.render(p)
+        st = device.stats()
+        assert all(st.kernel_ms[k] > 0 for k in range(12) if st.launches[k]), "every launched class is timed"
+        device.set_event_classes(1 << cabi.K_TRACE2)
+        device.render(p)
+        st = device.stats()
+        assert st.kernel_ms[cabi.K_TRACE2] > 0
+        assert all(st.kernel_ms[k] == 0 for k in range(12) if k != cabi.K_TRACE2)
+        assert st.launches[2] > 0, "launches are counted whether timed or not"
+    finally:
+        device.set_event_classes(0xffffffff)
+        device.set_profiling(events=False, counters=False)

@@ -10,6 +10,10 @@
 //   shadow   any-hit traversal of the shadow-ray list
 //   resolve  ordered sum of the unoccluded light samples
 //
+// The shadow rays of depth d and the bounce rays of depth d + 1 are both ready once
+// depth d is shaded and are traced by ONE launch (k_trace2); k_extend only traces
+// the camera rays and k_shadow the last depth's shadow rays.
+//
 // and finally `accumulate` folds the finished paths into the per-pixel sums in
 // sample order, applying the adaptive test between batches, exactly as
 // PathTracer::raytrace_pixel does (src/pathtracer/pathtracer.cpp:234-272 of the

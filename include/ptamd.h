@@ -198,7 +198,9 @@ int ptamd_render(ptamd_context *ctx, const ptamd_render_params *p, double *hdr_o
 /* Closest hit of camera rays through normalised sensor positions (sx, sy) in
  * [0,1]^2: Camera::generate_ray + BVHAccel::intersect (camera.cpp:190-203,
  * src/scene/bvh.cpp:164-200). prim_out is the primitive's index in desc order
- * (-1 = miss); t_out the hit distance. Host buffers of n entries. */
+ * (-1 = miss); t_out the hit distance. Host buffers of n entries. Uses the context's
+ * work buffers: it must not run while a ptamd_trace_list of the same context is still
+ * in flight (an open frame's parameters are left alone). */
 int ptamd_trace_primary(ptamd_context *ctx, int64_t n, const double *sx, const double *sy,
                         int32_t *prim_out, double *t_out);
 

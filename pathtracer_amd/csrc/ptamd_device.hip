@@ -35,6 +35,7 @@
 #include "../../include/ptamd.h"
 #include "device_math.h"
 #include "error_state.h"
+#include "fastdiv.h"
 
 using namespace ptdev;
 
@@ -973,17 +974,11 @@ struct ShadowPolicy {
   DevScene S;
   ShadowQ sq;
   VertexBuf vb;
-  uint32_t nls;
-  float inv_nls;
+  FastDiv by_nls;  // slot -> entry (exact for slot < 2^31, nls < 2^16: both enforced by ptamd_trace_list)
   __device__ __forceinline__ double min_t_all() const { return PT_EPS_D; }
   __device__ __forceinline__ bool load(uint32_t i, v3 &o, v3 &d, double &tmax) const {
     const int32_t slot = sq.slot[i];
-    // slot / nls through a float quotient and one correction: the generic 32-bit division is
-    // a long instruction sequence that holds a dozen registers (slot < 2^31, nls < 2^16)
-    uint32_t e = (uint32_t)((float)slot * inv_nls);
-    const int32_t rem = slot - (int32_t)(e * nls);
-    e += rem >= (int32_t)nls ? 1u : 0u;
-    e -= rem < 0 ? 1u : 0u;
+    const uint32_t e = by_nls.div((uint32_t)slot);
     o = V(vb.hp[0][e], vb.hp[1][e], vb.hp[2][e]);
     const SRay r = sq.ray[slot];
     d = V(r.d[0], r.d[1], r.d[2]);
@@ -1013,11 +1008,11 @@ struct ShadowPolicy {
 
 template <bool HEMI, bool COUNT>
 __global__ void TRAV_BOUNDS_N(PTAMD_WAVES_SHADOW)
-    k_shadow(DevScene S, ShadowQ sq, VertexBuf vb, Ctl *ctl, int32_t nls, uint2 *gstack) {
+    k_shadow(DevScene S, ShadowQ sq, VertexBuf vb, Ctl *ctl, FastDiv by_nls, uint2 *gstack) {
   extern __shared__ uint2 lds_stack[];
   const TravStack stack{(lds_uint2 *)lds_stack, gstack, gridDim.x * blockDim.x, blockIdx.x * blockDim.x + threadIdx.x, PTAMD_STACK_SHADOW};
   uint32_t cn = 0, ct = 0;
-  const ShadowPolicy<HEMI> pol{S, sq, vb, (uint32_t)nls, 1.0f / (float)nls};
+  const ShadowPolicy<HEMI> pol{S, sq, vb, by_nls};
   if (HEMI) trace_rays<0, COUNT, PTAMD_REFILL_SHADOW>(S, pol, ctl->n_shadow, &ctl->grab[1], stack, cn, ct);
   else trace_rays<1, COUNT, PTAMD_REFILL_SHADOW>(S, pol, ctl->n_shadow, &ctl->grab[1], stack, cn, ct);
   if (COUNT) {
@@ -1031,13 +1026,13 @@ __global__ void TRAV_BOUNDS_N(PTAMD_WAVES_SHADOW)
 template <bool HEMI, bool COUNT>
 __global__ void TRAV_BOUNDS_N(PTAMD_WAVES_EXTEND)
     k_trace2(DevScene S, RayQ q, const int32_t *__restrict__ list, HitBuf hb, ShadowQ sq, VertexBuf vb, Ctl *ctl,
-             int32_t nls, uint2 *gstack) {
+             FastDiv by_nls, uint2 *gstack) {
   extern __shared__ uint2 lds_stack[];
   const TravStack stack{(lds_uint2 *)lds_stack, gstack, gridDim.x * blockDim.x, blockIdx.x * blockDim.x + threadIdx.x, PTAMD_STACK_EXTEND};
   uint32_t cn = 0, ct = 0;
   const ExtendPolicy pe{q, list, hb, PT_EPS_D, (double)INFINITY};
   for (int k = 0; k < 3; k++) vb.hp[k] = q.o[k];  // the same arrays (see ptamd_trace_list): one set of pointers to hold
-  const ShadowPolicy<HEMI> ps{S, sq, vb, (uint32_t)nls, 1.0f / (float)nls};
+  const ShadowPolicy<HEMI> ps{S, sq, vb, by_nls};
   const uint32_t n_e = ctl->n_next, n_s = ctl->n_shadow;
   if (blockIdx.x == 0 && threadIdx.x == 0) {  // the only writer of these two during the launch
     ctl->st_two_ext += n_e;
@@ -1792,7 +1787,6 @@ int ensure_buffers(ptamd_context *c, int64_t paths, int nls, bool pend) {
   off_cp[0] = take(P);
   off_cp[1] = take((P / 256 + 2) * 4);
   off_cp[2] = take((P / 256 + 2) * 4);
-  size_t off_ctl = take(sizeof(Ctl));
   HIPCHK(hipMalloc(&c->slab, total));
   char *b = (char *)c->slab;
   for (int k = 0; k < 2; k++) {
@@ -1821,15 +1815,13 @@ int ensure_buffers(ptamd_context *c, int64_t paths, int nls, bool pend) {
   c->cp.pflag = (uint8_t *)(b + off_cp[0]);
   c->cp.cnt_next = (uint32_t *)(b + off_cp[1]);
   c->cp.cnt_shadow = (uint32_t *)(b + off_cp[2]);
-  c->ctl = (Ctl *)(b + off_ctl);
-  HIPCHK(hipMemset(c->ctl, 0, sizeof(Ctl)));
   c->cap_paths = paths;
   c->cap_nls = nls;
   c->cap_pend = true;
   return PTAMD_OK;
 }
 
-int setup_frame_params(ptamd_context *c, const ptamd_render_params *p) {
+int setup_frame_params(const ptamd_context *c, const ptamd_render_params *p, FrameParams &fp) {
   if (!c->have_scene || !c->have_camera) {
     ptamd::set_error("scene and camera must be set before rendering");
     return PTAMD_ERR_STATE;
@@ -1839,7 +1831,6 @@ int setup_frame_params(ptamd_context *c, const ptamd_render_params *p) {
     ptamd::set_error("invalid render parameters");
     return PTAMD_ERR_ARG;
   }
-  FrameParams &fp = c->fp;
   fp.w = p->w; fp.h = p->h;
   fp.max_ray_depth = p->max_ray_depth;
   fp.accum = p->accumulate_bounces ? 1 : 0;
@@ -1883,6 +1874,13 @@ int ptamd_create(int32_t device_id, ptamd_context **out) {
   if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) c->num_cu = prop.multiProcessorCount;
   if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) c->own_stream = nullptr;
   if (const char *e = getenv("PTAMD_TRACE_TWO")) c->trace_two = atoi(e) != 0;
+  // The counters live apart from the work buffers: those are reallocated when a later round needs
+  // more room, and a frame's statistics must survive that.
+  if (hipMalloc((void **)&c->ctl, sizeof(Ctl)) != hipSuccess || hipMemset(c->ctl, 0, sizeof(Ctl)) != hipSuccess) {
+    ptamd::set_error("cannot allocate the device-side counters");
+    ptamd_destroy(c);
+    return PTAMD_ERR_DEVICE;
+  }
   *out = c;
   return PTAMD_OK;
 }
@@ -1895,6 +1893,7 @@ void ptamd_destroy(ptamd_context *c) {
   for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
   free_scene(c);
   if (c->slab) (void)hipFree(c->slab);
+  if (c->ctl) (void)hipFree(c->ctl);
   if (c->block_count) (void)hipFree(c->block_count);
   if (c->gstack) (void)hipFree(c->gstack);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -2186,7 +2185,7 @@ int ptamd_set_camera(ptamd_context *c, const ptamd_camera *cam) {
 int ptamd_frame_begin(ptamd_context *c, const ptamd_render_params *p) {
   if (!c) { ptamd::set_error("null context"); return PTAMD_ERR_ARG; }
   HIPCHK(hipSetDevice(c->device));
-  int rc = setup_frame_params(c, p);
+  int rc = setup_frame_params(c, p, c->fp);
   if (rc) return rc;
   c->params = *p;
   c->fp.nls = light_samples_per_vertex(c, p, c->host_light_kinds);
@@ -2265,9 +2264,15 @@ int ptamd_trace_list(ptamd_context *c, const ptamd_pixel_list *list, int32_t sam
   hipStream_t s = (hipStream_t)stream;
   const FrameParams &fp = c->fp;
   const int nls = std::max(fp.nls, 1);
+  if (nls >= (1 << 16)) {
+    ptamd::set_error("more than 65535 light samples per vertex are not supported");
+    return PTAMD_ERR_ARG;
+  }
+  const FastDiv by_nls = make_fastdiv((uint32_t)nls);
   // paths per launch: max_paths, but never more than a 24 GB slab of work buffers
-  // (about 290 bytes per path + 70 per light-sample slot)
-  const int64_t by_memory = ((int64_t)24 << 30) / (290 + 70 * (int64_t)nls);
+  // (about 290 bytes per path + 70 per light-sample slot), and never so many that a light-sample
+  // slot index (entry * nls + q, an int32) would pass 2^31
+  const int64_t by_memory = std::min(((int64_t)24 << 30) / (290 + 70 * (int64_t)nls), (((int64_t)1 << 31) - 1) / nls);
   int64_t px_per_chunk = std::max<int64_t>(1, std::min(c->max_paths, by_memory) / n_samples);
   px_per_chunk = std::min(px_per_chunk, n);
   rc = ensure_buffers(c, px_per_chunk * n_samples, nls, !fp.accum);
@@ -2331,7 +2336,7 @@ int ptamd_trace_list(ptamd_context *c, const ptamd_pixel_list *list, int32_t sam
           // the hit records of this depth have been consumed by k_shade
           L.begin(PTAMD_K_TRACE2);
           const bool hemi = fp.hemisphere != 0, cnt = c->prof_counters;
-#define PTAMD_LAUNCH_TRACE2(H, C) hipLaunchKernelGGL((k_trace2<H, C>), egrid, tblock, elds, s, c->S, c->q[cur ^ 1], (const int32_t *)c->list[cur ^ 1], c->hb, c->sq, vb, c->ctl, nls, gstack)
+#define PTAMD_LAUNCH_TRACE2(H, C) hipLaunchKernelGGL((k_trace2<H, C>), egrid, tblock, elds, s, c->S, c->q[cur ^ 1], (const int32_t *)c->list[cur ^ 1], c->hb, c->sq, vb, c->ctl, by_nls, gstack)
           if (hemi) { if (cnt) PTAMD_LAUNCH_TRACE2(true, true); else PTAMD_LAUNCH_TRACE2(true, false); }
           else { if (cnt) PTAMD_LAUNCH_TRACE2(false, true); else PTAMD_LAUNCH_TRACE2(false, false); }
 #undef PTAMD_LAUNCH_TRACE2
@@ -2340,11 +2345,11 @@ int ptamd_trace_list(ptamd_context *c, const ptamd_pixel_list *list, int32_t sam
         } else {
           L.begin(PTAMD_K_SHADOW);
           if (fp.hemisphere) {
-            if (c->prof_counters) hipLaunchKernelGGL((k_shadow<true, true>), sgrid, tblock, slds, s, c->S, c->sq, vb, c->ctl, nls, gstack);
-            else hipLaunchKernelGGL((k_shadow<true, false>), sgrid, tblock, slds, s, c->S, c->sq, vb, c->ctl, nls, gstack);
+            if (c->prof_counters) hipLaunchKernelGGL((k_shadow<true, true>), sgrid, tblock, slds, s, c->S, c->sq, vb, c->ctl, by_nls, gstack);
+            else hipLaunchKernelGGL((k_shadow<true, false>), sgrid, tblock, slds, s, c->S, c->sq, vb, c->ctl, by_nls, gstack);
           } else {
-            if (c->prof_counters) hipLaunchKernelGGL((k_shadow<false, true>), sgrid, tblock, slds, s, c->S, c->sq, vb, c->ctl, nls, gstack);
-            else hipLaunchKernelGGL((k_shadow<false, false>), sgrid, tblock, slds, s, c->S, c->sq, vb, c->ctl, nls, gstack);
+            if (c->prof_counters) hipLaunchKernelGGL((k_shadow<false, true>), sgrid, tblock, slds, s, c->S, c->sq, vb, c->ctl, by_nls, gstack);
+            else hipLaunchKernelGGL((k_shadow<false, false>), sgrid, tblock, slds, s, c->S, c->sq, vb, c->ctl, by_nls, gstack);
           }
           L.end();
         }
@@ -2380,7 +2385,7 @@ int ptamd_filter_list(ptamd_context *c, const ptamd_pixel_list *in, int32_t n_do
   int rc = check_list(in, "ptamd_filter_list");
   if (rc) return rc;
   const int64_t n = shard_max(in);
-  if ((n_done < 2 && n_done != -1) || !d_n_out || (n > 0 && (!d_out || !d_state))) {
+  if ((n_done < 1 && n_done != -1) || !d_n_out || (n > 0 && (!d_out || !d_state))) {
     ptamd::set_error("invalid arguments to ptamd_filter_list");
     return PTAMD_ERR_ARG;
   }
@@ -2574,7 +2579,9 @@ int ptamd_trace_primary(ptamd_context *c, int64_t n, const double *sx, const dou
   if (!c || n < 0 || (n > 0 && (!sx || !sy || !prim_out || !t_out))) { ptamd::set_error("invalid arguments"); return PTAMD_ERR_ARG; }
   ptamd_render_params p{};
   p.w = 1; p.h = 1; p.x1 = 1; p.y1 = 1; p.ns_aa = 1; p.samples_per_batch = 1;
-  int rc = setup_frame_params(c, &p);
+  // (a frame that is open keeps its own parameters: these are local)
+  FrameParams fp{};
+  int rc = setup_frame_params(c, &p, fp);
   if (rc) return rc;
   HIPCHK(hipSetDevice(c->device));
   const int64_t chunk = std::min<int64_t>(std::max<int64_t>(n, 1), c->max_paths);
@@ -2594,8 +2601,8 @@ int ptamd_trace_primary(ptamd_context *c, int64_t n, const double *sx, const dou
     HIPCHK(hipMemcpyAsync(d_sx, sx + b, m * sizeof(double), hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(d_sy, sy + b, m * sizeof(double), hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_set_counts, 1, 1, 0, s, c->ctl, PixView{nullptr, nullptr, (long long)m, 0u, 1u}, 0u, (uint32_t)m, 1u);
-    hipLaunchKernelGGL(k_generate_primary, grid_for(c, 4), 256, 0, s, c->fp, d_sx, d_sy, (uint32_t)m, c->q[0]);
-    hipLaunchKernelGGL((k_extend<false>), tgrid, tblock, lds, s, c->S, c->q[0], (const int32_t *)nullptr, c->hb, c->ctl, c->fp.n_clip, c->fp.f_clip, tl.gstack);
+    hipLaunchKernelGGL(k_generate_primary, grid_for(c, 4), 256, 0, s, fp, d_sx, d_sy, (uint32_t)m, c->q[0]);
+    hipLaunchKernelGGL((k_extend<false>), tgrid, tblock, lds, s, c->S, c->q[0], (const int32_t *)nullptr, c->hb, c->ctl, fp.n_clip, fp.f_clip, tl.gstack);
     HIPCHK(hipMemcpyAsync(prim.data(), c->hb.prim, m * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(t_out + b, c->hb.t, m * sizeof(double), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));

@@ -57,6 +57,9 @@ CASES = [
     ("CBspheres_lambertian", 64, 48, dict(ns_aa=32, max_ray_depth=2, ns_area_light=2, hemisphere=True, accumulate_bounces=False)),
     ("CBempty", 64, 48, dict(ns_aa=32, max_ray_depth=4, ns_area_light=4)),
     ("CBcoil", 64, 48, dict(ns_aa=16, max_ray_depth=5, ns_area_light=2)),
+    # -a 1 tol: the adaptive test runs before every sample from the second on; at i = 1 it is
+    # 0 * inf = NaN, which lets the pixel go on (pathtracer.cpp:250-258)
+    ("CBspheres_lambertian", 48, 36, dict(ns_aa=12, max_ray_depth=2, ns_area_light=1, samples_per_batch=1, max_tolerance=0.3)),
 ]
 
 
@@ -126,6 +129,40 @@ def test_every_light_kind_matches_oracle(device, kind, param):
         assert close.mean() >= share, "kind %d keep_area %s: %.3f%% differ" % (kind, keep_area, 100 * (1 - close.mean()))
         if keep_area or kind == 2:  # lights at infinity alone cannot reach into the closed box
             assert hdr.max() > 0
+
+
+@pytest.mark.parametrize("nls,with_point", [(3, False), (5, True)])
+def test_light_sample_slots_beyond_2_pow_23(device, nls, with_point):
+    """One launch of 15.36 M path entries whose light-sample count per vertex is not a power of
+    two: a shadow ray finds its vertex through slot / nls, which must be exact for entry indices
+    above 2^23 (a float quotient is not). Checked against the oracle on the rows at the END of the
+    pixel list, whose entries have the largest indices."""
+    w, h = 800, 600
+    sc, arr, cam = _load("CBspheres_lambertian", w, h)
+    mod = arr
+    if with_point:
+        a = dict(arr.a)
+        rec = np.zeros(16)
+        rec[0:3] = 2.0
+        rec[3:6] = (0.1, 0.9, 0.3)
+        a["light_kind"] = np.concatenate([arr.a["light_kind"], [cabi.LIGHT_POINT]]).astype(np.int32)
+        a["light_param"] = np.concatenate([arr.a["light_param"], rec])
+        mod = cabi.SceneArrays(a, arr.root)
+    device.upload(mod)
+    device.set_camera(cam)
+    device.set_max_paths(0)
+    kw = dict(ns_aa=32, max_ray_depth=1, ns_area_light=nls - (1 if with_point else 0), seed=9)
+    hdr, cnt = device.render(cabi.make_params(w, h, **kw))
+    # the box spans about x 170..630, y 130..470 of this frame; rows 440..470 are entries 11.2 M to 12 M
+    rect = (300, 440, 500, 470)
+    rh, rc, _ = O.render(mod, cam, cabi.make_params(w, h, rect=rect, **kw), threads=8)
+    x0, y0, x1, y1 = rect
+    g, gc = hdr[y0:y1, x0:x1], cnt[y0:y1, x0:x1]
+    r, rcnt = rh[y0:y1, x0:x1], rc[y0:y1, x0:x1]
+    assert r.max() > 0 and (rcnt == 32).all()
+    assert np.array_equal(gc, rcnt)
+    close = np.isclose(g, r, rtol=1e-9, atol=1e-12).all(axis=2)
+    assert close.mean() >= 0.999, "%.3f%% of pixels differ beyond rounding" % (100 * (1 - close.mean()))
 
 
 def test_render_rectangle_only(device):

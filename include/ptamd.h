@@ -261,6 +261,18 @@ int ptamd_trace_list(ptamd_context *ctx, const ptamd_pixel_list *list, int32_t s
  * would (done at ns_aa samples, tested at every positive multiple of the batch). */
 int ptamd_filter_list(ptamd_context *ctx, const ptamd_pixel_list *in, int32_t n_done, const double *d_state,
                       int32_t *d_pixels_out, int64_t *d_n_out, void *stream);
+/* ptamd_filter_list for callers that cannot allocate device memory: code under HIP
+ * stream capture, tight serving loops, harnesses that forbid hipMalloc. (No counterpart
+ * in the reference; it exists for those callers only.) Same arguments, same result,
+ * bit for bit; the per-block counts its kernels need live in a static device array of
+ * PTAMD_FILTER_STATIC_MAX_PIXELS / 256 words (64 KiB per GPU, held until the process
+ * ends) instead of a buffer the library grows on demand, and the call makes no
+ * hipMalloc / hipFree / event creation. Lists longer than PTAMD_FILTER_STATIC_MAX_PIXELS
+ * entries (n_max, after offset / stride) are rejected with PTAMD_ERR_ARG. All calls on one
+ * GPU share that array: two calls that overlap in time on the same GPU race. */
+#define PTAMD_FILTER_STATIC_MAX_PIXELS (4 * 1024 * 1024)
+int ptamd_filter_list_static(ptamd_context *ctx, const ptamd_pixel_list *in, int32_t n_done,
+                             const double *d_state, int32_t *d_pixels_out, int64_t *d_n_out, void *stream);
 /* The exchange after a round, the counterpart of the reference's shared
  * sampleBuffer that every worker thread writes into (pathtracer.cpp:268-271):
  * pack gathers the state rows (6 doubles) of the shard's pixels into a dense

@@ -17,7 +17,7 @@ EXPORTS = (
     "ptamd_create", "ptamd_destroy", "ptamd_upload_scene", "ptamd_set_camera", "ptamd_set_max_paths",
     "ptamd_set_profiling", "ptamd_set_event_classes", "ptamd_render", "ptamd_trace_primary", "ptamd_frame_begin",
     "ptamd_trace_pixels", "ptamd_adaptive_filter", "ptamd_frame_resolve", "ptamd_get_stats",
-    "ptamd_trace_list", "ptamd_filter_list", "ptamd_pack_rows", "ptamd_unpack_rows",
+    "ptamd_trace_list", "ptamd_filter_list", "ptamd_filter_list_static", "ptamd_pack_rows", "ptamd_unpack_rows",
     "ptamd_tonemap_rgba8", "ptamd_write_png", "ptamd_write_png_top_down", "ptamd_sampling_rate_rgba8",
 )
 
@@ -69,6 +69,7 @@ def lib():
     pl = C.POINTER(PixelList)
     L.ptamd_trace_list.argtypes = [vp, pl, i32, i32, vp, vp]
     L.ptamd_filter_list.argtypes = [vp, pl, i32, vp, vp, vp, vp]
+    L.ptamd_filter_list_static.argtypes = [vp, pl, i32, vp, vp, vp, vp]
     L.ptamd_pack_rows.argtypes = [vp, pl, vp, vp, vp]
     L.ptamd_unpack_rows.argtypes = [vp, pl, i32, i32, vp, i64, vp, vp]
     L.ptamd_get_stats.argtypes = [vp, C.POINTER(Stats)]
@@ -188,6 +189,10 @@ class Device:
 
     def filter_list(self, plist, n_done, d_state, d_out, d_n_out, stream=0):
         _check(lib().ptamd_filter_list(self._h, C.byref(plist), n_done, d_state, d_out, d_n_out, stream))
+
+    def filter_list_static(self, plist, n_done, d_state, d_out, d_n_out, stream=0):
+        """filter_list without any device allocation (static scratch; lists up to FILTER_STATIC_MAX_PIXELS)."""
+        _check(lib().ptamd_filter_list_static(self._h, C.byref(plist), n_done, d_state, d_out, d_n_out, stream))
 
     def pack_rows(self, plist, d_state, d_rows, stream=0):
         _check(lib().ptamd_pack_rows(self._h, C.byref(plist), d_state, d_rows, stream))

@@ -1637,6 +1637,13 @@ __global__ void k_unpack_rows(PixView pv, uint32_t world, uint32_t skip_rank, co
   }
 }
 
+// Block counts of ptamd_filter_list_static: the one entry point that allocates nothing. Each GPU
+// the library runs on holds its own copy of this array, at its own address, until the process
+// ends; host code reaches it only through the pointer hipGetSymbolAddress returned on that GPU.
+constexpr int64_t FILTER_STATIC_MAX_PIXELS = PTAMD_FILTER_STATIC_MAX_PIXELS;
+constexpr size_t FILTER_STATIC_BLOCKS = (size_t)(FILTER_STATIC_MAX_PIXELS / 256);
+static __device__ __align__(256) uint32_t scratch[FILTER_STATIC_BLOCKS];
+
 }  // namespace
 
 // ====================================================================== host side
@@ -1681,6 +1688,7 @@ struct ptamd_context {
   Ctl *ctl = nullptr;
   uint32_t *block_count = nullptr;
   size_t block_count_cap = 0;
+  uint32_t *static_block_count = nullptr;  // this GPU's copy of `scratch` (ptamd_filter_list_static)
   uint2 *gstack = nullptr;  // overflow levels of the per-lane traversal stacks
   size_t gstack_bytes = 0;
   // profiling
@@ -1880,6 +1888,18 @@ int ptamd_create(int32_t device_id, ptamd_context **out) {
     ptamd::set_error("cannot allocate the device-side counters");
     ptamd_destroy(c);
     return PTAMD_ERR_DEVICE;
+  }
+  // Address of this device's copy of the static scratch array (the device is current: hipSetDevice
+  // above). The array's name is only a host-side handle; kernels and memsets get this pointer.
+  {
+    void *sp = nullptr;
+    const hipError_t e = hipGetSymbolAddress(&sp, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || !sp) {
+      ptamd::set_error(std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e));
+      ptamd_destroy(c);
+      return PTAMD_ERR_DEVICE;
+    }
+    c->static_block_count = (uint32_t *)sp;
   }
   *out = c;
   return PTAMD_OK;
@@ -2406,6 +2426,43 @@ int ptamd_filter_list(ptamd_context *c, const ptamd_pixel_list *in, int32_t n_do
   if (nb) hipLaunchKernelGGL(k_filter_scatter, nb, 256, 0, s, pv, n_done, c->params.max_tolerance, c->params.samples_per_batch,
                              c->params.ns_aa, d_state, c->block_count, d_out);
   L.end();
+  HIPCHK(hipGetLastError());
+  return PTAMD_OK;
+}
+
+// ptamd_filter_list with the per-block counts in the static device array instead of a buffer
+// the library allocates: no hipMalloc / hipFree / event creation on any path, so it may be
+// called where allocation is not allowed (under stream capture, in a serving loop). The
+// kernels are the same three; they get the array through the pointer taken at ptamd_create.
+// Nothing in the array has to start at zero: k_filter_count writes every count that
+// k_filter_scan and k_filter_scatter read. Calls that overlap on one GPU share the array and race.
+int ptamd_filter_list_static(ptamd_context *c, const ptamd_pixel_list *in, int32_t n_done, const double *d_state,
+                             int32_t *d_out, int64_t *d_n_out, void *stream) {
+  if (!c || !c->have_frame) { ptamd::set_error("ptamd_frame_begin must be called first"); return PTAMD_ERR_STATE; }
+  int rc = check_list(in, "ptamd_filter_list_static");
+  if (rc) return rc;
+  const int64_t n = shard_max(in);
+  if ((n_done < 1 && n_done != -1) || !d_n_out || (n > 0 && (!d_out || !d_state))) {
+    ptamd::set_error("invalid arguments to ptamd_filter_list_static");
+    return PTAMD_ERR_ARG;
+  }
+  if (n > FILTER_STATIC_MAX_PIXELS) {
+    ptamd::set_error("ptamd_filter_list_static: the list is longer than PTAMD_FILTER_STATIC_MAX_PIXELS; "
+                     "use ptamd_filter_list");
+    return PTAMD_ERR_ARG;
+  }
+  if (!c->static_block_count) { ptamd::set_error("static scratch array is not set up"); return PTAMD_ERR_STATE; }
+  HIPCHK(hipSetDevice(c->device));
+  hipStream_t s = (hipStream_t)stream;
+  const uint32_t nb = (uint32_t)((n + 255) / 256);
+  uint32_t *counts = c->static_block_count;
+  const PixView pv = view_of(in);
+  c->stats.launches[PTAMD_K_FILTER]++;
+  if (nb) hipLaunchKernelGGL(k_filter_count, nb, 256, 0, s, pv, n_done, c->params.max_tolerance, c->params.samples_per_batch,
+                             c->params.ns_aa, d_state, counts);
+  hipLaunchKernelGGL(k_filter_scan, 1, 1024, 0, s, counts, nb, (long long *)d_n_out);
+  if (nb) hipLaunchKernelGGL(k_filter_scatter, nb, 256, 0, s, pv, n_done, c->params.max_tolerance, c->params.samples_per_batch,
+                             c->params.ns_aa, d_state, counts, d_out);
   HIPCHK(hipGetLastError());
   return PTAMD_OK;
 }

@@ -134,6 +134,7 @@ typedef struct ptamd_stats {
   double kernel_ms[12];    /* summed HIP-event time per kernel class (profiling)  */
   uint64_t two_ext_rays;   /* bounce rays traced by launches of class PTAMD_K_TRACE2 */
   uint64_t two_shadow_rays;/* shadow rays traced by launches of class PTAMD_K_TRACE2 */
+  uint64_t exact_tests;    /* primitive tests the FP32 pre-test could not decide (counters enabled) */
 } ptamd_stats;
 
 /* kernel classes for ptamd_stats.launches / kernel_ms */

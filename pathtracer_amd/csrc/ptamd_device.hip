@@ -36,6 +36,7 @@
 #include "device_math.h"
 #include "error_state.h"
 #include "fastdiv.h"
+#include "prim32.h"
 
 using namespace ptdev;
 
@@ -46,7 +47,7 @@ namespace {
 // offsets on a per-node power-of-two grid, plus four child codes. The tree is the
 // reference's binary SAH tree collapsed two levels at a time, with every
 // primitive as its own child (so each primitive is culled by its own box before
-// its FP64 test). A code >= 0 is a node index, a negative code is primitive
+// its own test). A code >= 0 is a node index, a negative code is primitive
 // ~code, CHILD_EMPTY marks an unused slot.
 //
 // Why so small: the traversal kernels are bound by the number of 16-byte
@@ -59,26 +60,36 @@ namespace {
 // the decoded box CONTAINS the reference's FP64 box. Together with the
 // conservative float slab test below, a child is never culled when the
 // reference's FP64 test (src/scene/bbox.cpp:10-47) would have accepted it; which
-// hit wins is decided by FP64 primitive tests only.
+// hit wins is decided by the primitive tests only.
+//
+// The lower planes of the four children on one axis share a word (byte k: child k),
+// and so do the upper planes: which of the two a ray meets first depends only on the
+// sign of its direction, so the walk picks the near and the far WORD once per axis
+// instead of ordering two distances per child and axis.
 struct alignas(64) DevNode {
   float org[3];
   uint32_t exps;    // byte k: e_k as a signed 8-bit integer
-  uint8_t q[4][6];  // per child: lo.xyz, hi.xyz
+  uint32_t qlo[3];  // per axis: lower planes of children 0..3
+  uint32_t qhi[3];  // per axis: upper planes
   int32_t child[4];
   int32_t pad[2];
 };
 static_assert(sizeof(DevNode) == 64, "node must be half a cache line");
 constexpr int32_t CHILD_EMPTY = INT32_MIN;
 
-// Primitive record, 80 bytes (5 loads). Triangle: p1, e1 = p2-p1, e2 = p3-p1
-// rounded exactly as Triangle::test computes them on the fly
+// FP64 primitive record, 80 bytes (5 loads), read by exact_test. Triangle: p1,
+// e1 = p2-p1, e2 = p3-p1 rounded exactly as Triangle::test computes them on the fly
 // (src/scene/triangle.cpp:27); sphere: centre, r*r. The 10th slot holds
 // prim_info (bit 0: sphere, bits 1..: material) in its low 32 bits.
 constexpr int PRIM_STRIDE = 10;
+// FP32 pre-test record, 48 bytes (3 loads), the one the walk normally reads: p1 (or the
+// sphere's centre) as three doubles, so that o - p1 is formed in FP64 without cancellation
+// error, then e1, e2 as floats. A sphere has NaN in e1.x and float(r*r) in e1.y.
 
 struct DevScene {
   const DevNode *nodes;
   const double *prim;       // [n_prims * PRIM_STRIDE]
+  const uint4 *prim32;      // [n_prims * 3]: the FP32 pre-test's record, see ptamd_upload_scene
   const int32_t *prim_info; // bit 0: sphere, bits 1..: material index
   const double *prim_nrm;   // [n_prims * 9]
   const int32_t *mat_kind;
@@ -88,6 +99,7 @@ struct DevScene {
   const double *light_param;
   const double *jitter;
   int32_t n_lights, jitter_n, root_code, stack_cap;
+  float coord_bound;  // no ray starts farther from the origin than this on any axis (prim32.h: big)
 };
 
 struct FrameParams {
@@ -102,6 +114,7 @@ struct Ctl {
   uint32_t n_cur, n_next, n_shadow, n_pix;  // sizes of the ray lists; pixels of the running chunk
   uint32_t grab[4];  // next unclaimed ray of a list: [0] k_extend, [1] shadow rays, [2] bounce rays in k_trace2 (persistent drivers)
   unsigned long long st_rays, st_shadow, st_vertices, st_nodes, st_tests, st_samples, st_dead;
+  unsigned long long st_exact;  // primitive tests that needed the FP64 path (counted with st_tests)
   unsigned long long st_two_ext, st_two_shadow;  // rays of either kind traced by k_trace2 launches
 };
 
@@ -128,7 +141,7 @@ struct RayQ {
 };
 struct HitBuf {
   int32_t *prim;
-  double *t, *u, *v;
+  double *t;  // only ptamd_trace_primary asks for distances
 };
 // Per light sample (slot = entry * nls + q) the records are arrays of structures
 // (shadow ray 32 bytes, contribution 24): the nls samples of one vertex are written by
@@ -150,6 +163,12 @@ struct VertexBuf {
   uint8_t *flag;     // bit 0: has light samples, bit 1: result goes to `pending`
   Contrib *contrib;  // [cap * nls]
   uint8_t *vis;      // [cap * nls]
+  // The primitive a vertex lies on, as a child code, when every ray leaving the vertex may skip it
+  // (see k_shade), else CHILD_EMPTY; and the |D| above which the reference's test of that primitive
+  // certainly fails its min_t clause.
+  int32_t *self_code;  // [cap]
+  float *self_dmin;    // [cap]
+  int32_t *pend_prim;  // [cap * nls] primitive a shadow ray could not decide in FP32 (vis = 3), for k_resolve
 };
 struct PathBuf {
   double *rad[3];
@@ -226,13 +245,21 @@ struct RoundPlan {
 struct RayF {
   float inv[3];
 };
+// the largest float <= x and the smallest float >= x (x not NaN). Stepping to the neighbouring
+// float is an integer step on the bit pattern: away from zero adds one, towards zero subtracts
+// one, and from +-0 the neighbour is the smallest subnormal of the wanted sign.
+__device__ __forceinline__ float f_step(float f, bool up) {
+  const uint32_t b = __float_as_uint(f);
+  if ((b << 1) == 0u) return __uint_as_float(up ? 1u : 0x80000001u);
+  return __uint_as_float(((b >> 31) != 0u) == up ? b - 1u : b + 1u);
+}
 __device__ __forceinline__ float f_down(double x) {
-  float f = (float)x;
-  return ((double)f > x) ? nextafterf(f, -INFINITY) : f;
+  const float f = (float)x;
+  return ((double)f > x) ? f_step(f, false) : f;
 }
 __device__ __forceinline__ float f_up(double x) {
-  float f = (float)x;
-  return ((double)f < x) ? nextafterf(f, INFINITY) : f;
+  const float f = (float)x;
+  return ((double)f < x) ? f_step(f, true) : f;
 }
 __device__ __forceinline__ RayF make_rayf(v3 d) {
   RayF r;
@@ -264,15 +291,21 @@ __device__ __forceinline__ RayF make_rayf(v3 d) {
 #ifndef PTAMD_GRID_MULT
 #define PTAMD_GRID_MULT 8
 #endif
+#ifndef PTAMD_TRIP
+#define PTAMD_TRIP 0
+#endif
 #ifndef PTAMD_NODE_STEPS
 #define PTAMD_NODE_STEPS 2
 #endif
 // idle lanes at which a persistent wave refills (0: grid-stride driver), see trace_rays
 #ifndef PTAMD_REFILL_EXTEND
-#define PTAMD_REFILL_EXTEND 16
+#define PTAMD_REFILL_EXTEND 24
 #endif
 #ifndef PTAMD_REFILL_SHADOW
-#define PTAMD_REFILL_SHADOW 32
+#define PTAMD_REFILL_SHADOW 48
+#endif
+#ifndef PTAMD_REFILL_TWO_S
+#define PTAMD_REFILL_TWO_S 40  // the shadow-ray list of k_trace2
 #endif
 #ifndef PTAMD_WAVES_EXTEND
 #define PTAMD_WAVES_EXTEND 5  // the closest-hit walk with lane refill needs ~96 registers; spilling costs more than a wave
@@ -316,8 +349,8 @@ struct TravStack {
 };
 
 struct Hit {
-  double t, u, v;
-  int32_t prim;
+  int32_t prim;  // -1: none
+  bool certain;  // first-hit walks: false = `prim` is a primitive the FP32 test could not decide (and no other occludes)
 };
 
 __device__ __forceinline__ void cswap(float &ta, int32_t &ca, float &tb, int32_t &cb) {
@@ -327,39 +360,87 @@ __device__ __forceinline__ void cswap(float &ta, int32_t &ca, float &tb, int32_t
   }
 }
 
+// The reference's FP64 test of primitive p (Triangle::test, src/scene/triangle.cpp:25-44;
+// Sphere::test / Sphere::intersect, src/scene/sphere.cpp:11-72) in its operation order,
+// WITHOUT the max_t clause: false when the reference rejects the primitive for any other
+// reason; else t (u, v for a triangle) are the values it computes. For a sphere t is the
+// first root that is not below min_t: the reference takes the first root inside
+// [min_t, max_t], and when the first root at or beyond min_t lies beyond max_t so does the
+// second, so comparing this t with max_t decides as the reference does.
+__device__ __forceinline__ bool exact_test(const DevScene &S, int p, const v3 &o, const v3 &d, double min_t, double &t,
+                                           double &u, double &v) {
+  const double *P = S.prim + (size_t)p * PRIM_STRIDE;
+  const int32_t info = reinterpret_cast<const int32_t *>(P + 9)[0];
+  t = 0; u = 0; v = 0;
+  if (!(info & 1)) {
+    const v3 p1 = V(P[0], P[1], P[2]), e1 = V(P[3], P[4], P[5]), e2 = V(P[6], P[7], P[8]);
+    const v3 normal = vcross(e1, e2);
+    if (vdot(normal, d) == 0) return false;
+    const v3 sv = vsub(o, p1), s1 = vcross(d, e2), s2 = vcross(sv, e1);
+    const double rse1 = 1 / (vdot(s1, e1));
+    t = vdot(s2, e2) * rse1;
+    u = vdot(s1, sv) * rse1;
+    v = vdot(s2, d) * rse1;
+    return !(t < min_t || u < 0 || v < 0 || u + v > 1);
+  }
+  const v3 c = V(P[0], P[1], P[2]);
+  const double r2 = P[3];
+  const v3 ominc = vsub(o, c);
+  const double a = vdot(d, d), b = 2 * vdot(ominc, d), cc = vdot(ominc, ominc) - r2;
+  const double discr = b * b - 4 * a * cc;
+  if (discr < 0) return false;
+  const double r2a = 1 / (2 * a);
+  const double b2a = -b * r2a, sq = sqrt(discr) * r2a;
+  const double t1 = b2a - sq, t2 = b2a + sq;
+  if (t1 >= min_t) { t = t1; return true; }
+  if (t2 >= min_t) { t = t2; return true; }
+  return false;
+}
+
 // State of one ray's walk.
 //
 // The reference walks its binary tree with an explicit stack in a fixed order
-// and keeps the first of equally distant hits (src/scene/bvh.cpp:164-200).
-// Primitives are stored here in exactly that visiting order, so "closest t, then
-// lowest index" reproduces its answer for ANY traversal order and ANY tree over
-// the same primitives; this walk takes the nearest child of a 4-wide node first
-// and drops stacked subtrees that start beyond the current hit. Primitive tests
-// are the reference's, in FP64.
+// and keeps the first of equally distant hits (src/scene/bvh.cpp:164-200):
+// its answer is the primitive with the smallest t below the ray's max_t, and
+// among equal t the one it visits first. Primitives are stored here in exactly
+// that visiting order, so "closest t, then lowest index" reproduces its answer
+// for ANY traversal order and ANY tree over the same primitives; this walk takes
+// the nearest child of a 4-wide node first and drops stacked subtrees that start
+// beyond the current hit.
+//
+// Primitive tests run in FP32 with error bounds (prim32.h) and the walk keeps the
+// candidate hit as (primitive, [lo_f, best_f]): an interval that contains the
+// distance the reference computes for it. A primitive certainly missed costs nothing
+// more; a certain hit whose interval lies entirely below the candidate's replaces it;
+// only when the FP32 answer is not certain, or two intervals overlap, does the walk
+// run the reference's FP64 test (exact_test) on the primitives in question and compare
+// the exact distances (and indices). Without a hit the interval is the ray's own max_t
+// rounded down and up. The exact t, u, v of the final hit are computed once, by the
+// kernel that shades it (k_shade), with every lane busy.
 struct Walk {
   v3 o, d;
   RayF rf;
-  double best_t;
-  float best_f;
-  // the hit so far; its distance is best_t (an accepted hit always shortens the ray to its own t,
-  // and without a hit both are the ray's max_t)
-  // Its barycentrics do not stay in registers: the policy's record() writes them to the hit buffer
-  // every time a closer hit is found (a ray finds about 1.5), which is cheaper than four registers.
+  float lo_f, best_f;
   int32_t hit_prim;
   int sp;
   int32_t cur;
-  __device__ __forceinline__ Hit result() const { return Hit{best_t, 0.0, 0.0, hit_prim}; }
+  float cur_t;        // where the ray enters cur's box (the box test's conservative near distance)
+  int32_t self_code;  // the primitive the ray starts on, when it may be skipped (VertexBuf::self_code)
+  // (a first-hit walk that has found a certain occluder says so with lo_f = NaN)
+  __device__ __forceinline__ Hit result() const { return Hit{hit_prim, lo_f != lo_f}; }
 
-  // (min_t is the same for every ray of a launch: the drivers hold it, and m0 = max(min_t rounded
-  // down, 0) for the box test, in scalar registers instead of two and one per lane)
-  __device__ __forceinline__ void begin(const DevScene &S, v3 o_, v3 d_, double tmax) {
+  // (min_t is the same for every ray of a launch: the drivers hold it, and its float
+  // neighbours, in scalar registers)
+  __device__ __forceinline__ void begin(const DevScene &S, v3 o_, v3 d_, double tmax, int32_t self) {
     o = o_; d = d_;
+    self_code = self;
     rf = make_rayf(d);
-    best_t = tmax;
+    lo_f = f_down(tmax);
     best_f = f_up(tmax);
     hit_prim = -1;
     sp = 0;
     cur = S.root_code;
+    cur_t = 0.f;
   }
 
   // pop, skipping subtrees that begin beyond the current hit
@@ -371,6 +452,7 @@ struct Walk {
         const uint2 e = stack.get_lds(sp);
         if (__uint_as_float(e.y) > best_f) continue;
         cur = (int32_t)e.x;
+        cur_t = __uint_as_float(e.y);
         break;
       }
     } else {
@@ -379,6 +461,7 @@ struct Walk {
         const uint2 e = stack.get(sp);
         if (__uint_as_float(e.y) > best_f) continue;
         cur = (int32_t)e.x;
+        cur_t = __uint_as_float(e.y);
         break;
       }
     }
@@ -389,13 +472,16 @@ struct Walk {
   __device__ __forceinline__ void node_step(const DevScene &S, const TravStack &stack, uint32_t &n_nodes, float m0) {
     const float FINF = INFINITY;
     const uint4 *np = reinterpret_cast<const uint4 *>(S.nodes + cur);
-    const uint4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3];
+    const uint4 w0 = np[0], w1 = np[1], w2 = np[2];
+    const uint2 w3 = *reinterpret_cast<const uint2 *>(np + 3);
     if (COUNT) n_nodes += 4;
     const float org[3] = {__uint_as_float(w0.x), __uint_as_float(w0.y), __uint_as_float(w0.z)};
+    const uint32_t qlo[3] = {w1.x, w1.y, w1.z}, qhi[3] = {w1.w, w2.x, w2.y};
     // float(o) and the slack |of inv| 2^-22 are recomputed here rather than carried by the walk:
     // six registers less per lane are worth more than the nine instructions
     const float of[3] = {(float)o.x, (float)o.y, (float)o.z};
-    float A[3], Blo[3], Bhi[3];
+    float A[3], Bn[3], Bf[3];
+    uint32_t qn[3], qf[3];
 #pragma unroll
     for (int a = 0; a < 3; a++) {
       const int e = (int)(w0.w << (24 - 8 * a)) >> 24;  // signed byte a
@@ -403,30 +489,27 @@ struct Walk {
       const float B = (org[a] - of[a]) * rf.inv[a];
       const float slack = fabsf(of[a] * rf.inv[a]) * 2.38418579e-07f;  // 2^-22
       const float E = fmaf(fmaf(fabsf(A[a]), 255.f, fabsf(B)), 9.53674316e-07f /* 2^-20 */, slack);
-      const float cE = copysignf(E, A[a]);
-      Blo[a] = B - cE;
-      Bhi[a] = B + cE;
+      // the plane met first is the lower one when the ray runs up the axis, else the upper one
+      const bool down = rf.inv[a] < 0.f;
+      qn[a] = down ? qhi[a] : qlo[a];
+      qf[a] = down ? qlo[a] : qhi[a];
+      Bn[a] = B - E;
+      Bf[a] = B + E;
     }
-    // 24 quantised bytes: w1.xyzw, w2.xy; codes: w2.zw, w3.xy
-    const uint32_t qw[6] = {w1.x, w1.y, w1.z, w1.w, w2.x, w2.y};
     int32_t c[4] = {(int32_t)w2.z, (int32_t)w2.w, (int32_t)w3.x, (int32_t)w3.y};
     float t[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-      float tn = -FINF, tf = FINF;
+      float tn[3], tf[3];
 #pragma unroll
       for (int a = 0; a < 3; a++) {
-        const int bl = k * 6 + a, bh = k * 6 + 3 + a;
-        const float ql = (float)((qw[bl >> 2] >> ((bl & 3) * 8)) & 0xffu);
-        const float qh = (float)((qw[bh >> 2] >> ((bh & 3) * 8)) & 0xffu);
-        const float tl = fmaf(ql, A[a], Blo[a]);
-        const float th = fmaf(qh, A[a], Bhi[a]);
-        tn = fmaxf(tn, fminf(tl, th));
-        tf = fminf(tf, fmaxf(tl, th));
+        tn[a] = fmaf((float)((qn[a] >> (8 * k)) & 0xffu), A[a], Bn[a]);
+        tf[a] = fmaf((float)((qf[a] >> (8 * k)) & 0xffu), A[a], Bf[a]);
       }
-      // bbox.cpp:38 with NaNs (dropped above) accepting: reject iff
-      // max(tn, min_t, 0) > min(tf, max_t)
-      const float lo2 = fmaxf(tn, m0), hi2 = fminf(tf, best_f);
+      // bbox.cpp:38 with NaNs (a direction component of zero; fmaxf / fminf drop them) accepting:
+      // reject iff max(tn, min_t, 0) > min(tf, max_t)
+      const float lo2 = fmaxf(fmaxf(fmaxf(tn[0], tn[1]), tn[2]), m0);
+      const float hi2 = fminf(fminf(fminf(tf[0], tf[1]), tf[2]), best_f);
       t[k] = (c[k] != CHILD_EMPTY && !(lo2 > hi2)) ? lo2 : FINF;
     }
     cswap(t[0], c[0], t[1], c[1]);
@@ -449,67 +532,116 @@ struct Walk {
       }
       sp += nv;
       cur = c[0];
+      cur_t = t[0];
     } else {
       pop(stack);
     }
   }
 
-  // cur is a primitive: the reference's FP64 test; returns true when the walk is over.
+  // cur is a primitive: FP32 test, FP64 only when that is not certain (see above); returns true
+  // when the walk is over.
   // ANY: 0 closest hit, 1 first hit, 2 per ray (`first_hit`)
-  // rec(u, v): called when a hit is recorded as the closest so far
-  template <int ANY, bool COUNT, class Rec>
-  __device__ __forceinline__ bool prim_step(const DevScene &S, const TravStack &stack, uint32_t &n_tests, double min_t,
-                                            const Rec &rec, bool first_hit = false) {
+  // ray_end(): the ray's own FP64 max_t (asked for only on the FP64 path)
+  // self_dmin(): VertexBuf::self_dmin of the vertex the ray leaves (asked for at the primitive it starts on)
+  // min_lo <= min_t <= min_hi: its float neighbours
+  //
+  // Two questions come up on almost every ray and cannot be settled in FP32: the primitive the ray
+  // starts on (t = 0 up to FP64 rounding, against min_t = 1e-11) and, for a shadow ray, the light's own
+  // primitive at its far end (t = max_t up to rounding). The first is settled by the kernel that
+  // made the ray (self_code / self_dmin). The second is left open: a first-hit walk remembers ONE
+  // undecided primitive and goes on looking for a certain occluder; if none turns up, the kernel
+  // that consumes the ray (k_resolve) runs the reference's test on that primitive, with every
+  // lane busy. Only a second undecided primitive is tested in FP64 on the spot.
+  template <int ANY, bool COUNT, class End, class Dmin>
+  __device__ __forceinline__ bool prim_step(const DevScene &S, const TravStack &stack, uint32_t &n_tests, uint32_t &n_exact,
+                                            double min_t, float min_lo, float min_hi, const End &ray_end,
+                                            const Dmin &self_dmin, bool first_hit = false) {
     const int p = (int)~(uint32_t)cur;
     if (COUNT) n_tests++;
-    const double *P = S.prim + (size_t)p * PRIM_STRIDE;
-    const int32_t info = reinterpret_cast<const int32_t *>(P + 9)[0];
-    double t = 0, u = 0, v = 0;
-    bool ok = false;
-    if (!(info & 1)) {
-      // Triangle::test, src/scene/triangle.cpp:25-44
-      const v3 p1 = V(P[0], P[1], P[2]), e1 = V(P[3], P[4], P[5]), e2 = V(P[6], P[7], P[8]);
-      const v3 normal = vcross(e1, e2);
-      if (vdot(normal, d) != 0) {
-        const v3 sv = vsub(o, p1), s1 = vcross(d, e2), s2 = vcross(sv, e1);
-        const double rse1 = 1 / (vdot(s1, e1));
-        t = vdot(s2, e2) * rse1;
-        u = vdot(s1, sv) * rse1;
-        v = vdot(s2, d) * rse1;
-        ok = !(t < min_t || t > best_t || u < 0 || v < 0 || u + v > 1);
-      }
-    } else {
-      // Sphere::test / Sphere::intersect, src/scene/sphere.cpp:11-72
-      const v3 c = V(P[0], P[1], P[2]);
-      const double r2 = P[3];
-      const v3 ominc = vsub(o, c);
-      const double a = vdot(d, d), b = 2 * vdot(ominc, d), cc = vdot(ominc, ominc) - r2;
-      const double discr = b * b - 4 * a * cc;
-      if (!(discr < 0)) {
-        const double r2a = 1 / (2 * a);
-        const double b2a = -b * r2a, sq = sqrt(discr) * r2a;
-        const double t1 = b2a - sq, t2 = b2a + sq;
-        if (t1 <= best_t && t1 >= min_t) { t = t1; ok = true; }
-        else if (t2 <= best_t && t2 >= min_t) { t = t2; ok = true; }
-      }
-    }
-    if (ok) {
-      // ok means min_t <= t <= best_t. Every such hit shortens the ray
-      // (r.max_t = t); it is RECORDED when strictly closer than anything before
-      // (bvh.cpp:187), or equally close as the recorded hit but earlier in the
-      // reference's visiting order (lower index here).
-      if (ANY == 1 || (ANY == 2 && first_hit)) {
-        // (best_t is still the ray's own max_t: a first-hit walk ends at its first hit)
-        if (t < best_t) { hit_prim = p; best_t = t; return true; }
-      } else if (t < best_t || (hit_prim >= 0 && p < hit_prim)) {
+    const uint4 *R = S.prim32 + (size_t)p * 3;
+    const uint4 r0 = R[0], r1 = R[1], r2 = R[2];
+    float dmin = INFINITY;
+    if (cur == self_code) dmin = self_dmin();
+    const double p1x = __hiloint2double((int)r0.y, (int)r0.x), p1y = __hiloint2double((int)r0.w, (int)r0.z),
+                 p1z = __hiloint2double((int)r1.y, (int)r1.x);
+    // the origin moved to where the ray enters the primitive's box (prim32.h)
+    const double t0 = (double)cur_t;
+    const float sv[3] = {(float)(fma(t0, d.x, o.x) - p1x), (float)(fma(t0, d.y, o.y) - p1y), (float)(fma(t0, d.z, o.z) - p1z)};
+    const float big = S.coord_bound + fabsf(cur_t);
+    const float df[3] = {(float)d.x, (float)d.y, (float)d.z};
+    const float e1[3] = {__uint_as_float(r1.z), __uint_as_float(r1.w), __uint_as_float(r2.x)};
+    const float e2[3] = {__uint_as_float(r2.y), __uint_as_float(r2.z), __uint_as_float(r2.w)};
+    float lo = 0.f, hi = 0.f;
+    int cls;
+    if (e1[0] == e1[0]) cls = classify_tri32(sv, df, e1, e2, min_lo, min_hi, best_f, dmin, cur_t, big, lo, hi);
+    else cls = classify_sphere32(sv, df, e1[1], min_lo, min_hi, best_f, cur_t, big, lo, hi);  // NaN marks a sphere; e1[1] = r^2
+    const bool first = ANY == 1 || (ANY == 2 && first_hit);
+    bool unsure = cls == PT32_UNSURE;
+    if (cls == PT32_HIT) {
+      if (hi < lo_f) {  // certainly closer than the candidate, or than the ray's own end
         hit_prim = p;
-        rec(u, v);
+        if (first) {
+          lo_f = NAN;
+        } else {
+          lo_f = lo;
+          best_f = hi;
+        }
+      } else {
+        unsure = true;
       }
-      best_t = t;
-      best_f = f_up(t);
     }
+    if (unsure) {
+      if (first && hit_prim < 0) {
+        hit_prim = p;  // left to the consumer of the ray
+      } else {
+        if (COUNT) n_exact++;
+        double t, u, v;
+        if (exact_test(S, p, o, d, min_t, t, u, v)) {
+          if (first) {
+            if (t < ray_end()) { hit_prim = p; lo_f = NAN; }
+          } else if (hit_prim < 0) {
+            // (bvh.cpp:187: a hit counts when strictly closer than the ray's end)
+            if (t < ray_end()) { hit_prim = p; lo_f = f_down(t); best_f = f_up(t); }
+          } else {
+            double tc, uc, vc;
+            exact_test(S, hit_prim, o, d, min_t, tc, uc, vc);
+            if (t < tc || (t == tc && p < hit_prim)) hit_prim = p;
+            else t = tc;
+            lo_f = f_down(t);
+            best_f = f_up(t);
+          }
+        }
+      }
+    }
+    if (first && lo_f != lo_f) return true;
     pop(stack);
     return cur == CHILD_EMPTY;
+  }
+
+  // One trip of an active lane; true when its walk is over. PTAMD_TRIP 0: PTAMD_NODE_STEPS box
+  // steps, then a primitive test for the lanes at a primitive (which includes lanes a box step
+  // has just brought there); 1: a primitive test after every box step.
+  template <int ANY, bool COUNT, class End, class Dmin>
+  __device__ __forceinline__ bool trip(const DevScene &S, const TravStack &stack, uint32_t &n_nodes, uint32_t &n_tests,
+                                       uint32_t &n_exact, float m0, double min_t, float min_lo, float min_hi,
+                                       const End &ray_end, const Dmin &self_dmin, bool first_hit = false) {
+#if PTAMD_TRIP == 0
+#pragma unroll
+    for (int k = 0; k < PTAMD_NODE_STEPS; k++)
+      if (cur >= 0) node_step<COUNT>(S, stack, n_nodes, m0);
+    if (cur == CHILD_EMPTY) return true;
+    if (cur < 0) return prim_step<ANY, COUNT>(S, stack, n_tests, n_exact, min_t, min_lo, min_hi, ray_end, self_dmin, first_hit);
+    return false;
+#else
+#pragma unroll
+    for (int k = 0; k < PTAMD_NODE_STEPS; k++) {
+      if (cur >= 0) node_step<COUNT>(S, stack, n_nodes, m0);
+      if (cur < 0 && cur != CHILD_EMPTY &&
+          prim_step<ANY, COUNT>(S, stack, n_tests, n_exact, min_t, min_lo, min_hi, ray_end, self_dmin, first_hit))
+        return true;
+    }
+    return cur == CHILD_EMPTY;
+#endif
   }
 };
 
@@ -586,24 +718,21 @@ struct Claims {
 
 template <int ANY, bool COUNT, int REFILL, class Policy>
 __device__ __forceinline__ void trace_rays(const DevScene &S, const Policy &pol, uint32_t n, uint32_t *grab,
-                                           const TravStack &stack, uint32_t &n_nodes, uint32_t &n_tests) {
+                                           const TravStack &stack, uint32_t &n_nodes, uint32_t &n_tests, uint32_t &n_exact) {
   Walk w;
   const double min_t = pol.min_t_all();
-  const float m0 = fmaxf(f_down(min_t), 0.f);
+  const float min_lo = f_down(min_t), min_hi = f_up(min_t);
+  const float m0 = fmaxf(min_lo, 0.f);
   if (REFILL == 0) {
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
       v3 o, d;
       double tmax;
-      if (!pol.load(i, o, d, tmax)) continue;
-      w.begin(S, o, d, tmax);
-      while (w.cur != CHILD_EMPTY) {
-#pragma unroll
-        for (int k = 0; k < PTAMD_NODE_STEPS; k++)
-          if (w.cur >= 0) w.template node_step<COUNT>(S, stack, n_nodes, m0);
-        if (w.cur < 0 && w.cur != CHILD_EMPTY &&
-            w.template prim_step<ANY, COUNT>(S, stack, n_tests, min_t, [&](double u, double v) { pol.record(i, u, v); }))
-          break;
+      int32_t self;
+      if (!pol.load(i, o, d, tmax, self)) continue;
+      w.begin(S, o, d, tmax, self);
+      while (!w.template trip<ANY, COUNT>(S, stack, n_nodes, n_tests, n_exact, m0, min_t, min_lo, min_hi,
+                                          [&]() { return pol.ray_end(i); }, [&]() { return pol.self_dmin(i); })) {
       }
       pol.store(i, w.result(), w.hit_prim >= 0);
     }
@@ -631,8 +760,9 @@ __device__ __forceinline__ void trace_rays(const DevScene &S, const Policy &pol,
           idx = mine;
           v3 o, d;
           double tmax;
-          if (pol.load(idx, o, d, tmax)) {
-            w.begin(S, o, d, tmax);
+          int32_t self;
+          if (pol.load(idx, o, d, tmax, self)) {
+            w.begin(S, o, d, tmax, self);
             active = true;
           }
         }
@@ -644,13 +774,8 @@ __device__ __forceinline__ void trace_rays(const DevScene &S, const Policy &pol,
       continue;
     }
     if (active) {
-#pragma unroll
-      for (int k = 0; k < PTAMD_NODE_STEPS; k++)
-        if (w.cur >= 0) w.template node_step<COUNT>(S, stack, n_nodes, m0);
-      bool done = w.cur == CHILD_EMPTY;
-      if (!done && w.cur < 0)
-        done = w.template prim_step<ANY, COUNT>(S, stack, n_tests, min_t, [&](double u, double v) { pol.record(idx, u, v); }) ||
-               w.cur == CHILD_EMPTY;
+      const bool done = w.template trip<ANY, COUNT>(S, stack, n_nodes, n_tests, n_exact, m0, min_t, min_lo, min_hi,
+                                                    [&]() { return pol.ray_end(idx); }, [&]() { return pol.self_dmin(idx); });
       if (done) {
         pol.store(idx, w.result(), w.hit_prim >= 0);
         active = false;
@@ -670,10 +795,11 @@ __device__ __forceinline__ void trace_rays(const DevScene &S, const Policy &pol,
 template <bool CLOSEST_S, bool COUNT, int REFILL, class PolE, class PolS>
 __device__ __forceinline__ void trace_two_lists(const DevScene &S, const PolE &pe, uint32_t n_e, uint32_t *grab_e,
                                                 const PolS &ps, uint32_t n_s, uint32_t *grab_s, const TravStack &stack,
-                                                uint32_t &n_nodes, uint32_t &n_tests) {
+                                                uint32_t &n_nodes, uint32_t &n_tests, uint32_t &n_exact) {
   Walk w;
   const double min_t = pe.min_t_all();  // == ps.min_t_all(): both kinds of ray leave a surface
-  const float m0 = fmaxf(f_down(min_t), 0.f);
+  const float min_lo = f_down(min_t), min_hi = f_up(min_t);
+  const float m0 = fmaxf(min_lo, 0.f);
   const uint32_t waves = gridDim.x * (TRAV_BLOCK / 64u);
   const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (TRAV_BLOCK / 64u) + (threadIdx.x >> 6)));
   const int lane = threadIdx.x & 63;
@@ -689,7 +815,9 @@ __device__ __forceinline__ void trace_two_lists(const DevScene &S, const PolE &p
   for (;;) {
     const unsigned long long idle = __ballot(!active);
     const int n_idle = __popcll(idle);
-    if (n_idle >= REFILL && phase < 2) {
+    // (short first-hit walks pay relatively more for a refill pass than long closest-hit walks:
+    // their list is refilled in bigger groups)
+    if (n_idle >= (phase == 0 ? REFILL : PTAMD_REFILL_TWO_S) && phase < 2) {
       if (next >= end) {
         const bool got = own_chunk ? cl.first(wave, next, end) : cl.more(lane, next, end);
         own_chunk = false;
@@ -705,9 +833,10 @@ __device__ __forceinline__ void trace_two_lists(const DevScene &S, const PolE &p
         idx = mine;
         v3 o, d;
         double tmax;
-        const bool have = phase == 0 ? pe.load(idx, o, d, tmax) : ps.load(idx, o, d, tmax);
+        int32_t self;
+        const bool have = phase == 0 ? pe.load(idx, o, d, tmax, self) : ps.load(idx, o, d, tmax, self);
         if (have) {
-          w.begin(S, o, d, tmax);
+          w.begin(S, o, d, tmax, self);
           active = true;
           from_s = phase == 1;
         }
@@ -719,15 +848,10 @@ __device__ __forceinline__ void trace_two_lists(const DevScene &S, const PolE &p
       continue;
     }
     if (active) {
-#pragma unroll
-      for (int k = 0; k < PTAMD_NODE_STEPS; k++)
-        if (w.cur >= 0) w.template node_step<COUNT>(S, stack, n_nodes, m0);
-      bool done = w.cur == CHILD_EMPTY;
-      if (!done && w.cur < 0)
-        done = w.template prim_step<2, COUNT>(S, stack, n_tests, min_t,
-                                              [&](double u, double v) { if (!from_s) pe.record(idx, u, v); },
-                                              !CLOSEST_S && from_s) ||
-               w.cur == CHILD_EMPTY;
+      const bool done = w.template trip<2, COUNT>(S, stack, n_nodes, n_tests, n_exact, m0, min_t, min_lo, min_hi,
+                                                  [&]() { return from_s ? ps.ray_end(idx) : pe.ray_end(idx); },
+                                                  [&]() { return from_s ? ps.self_dmin(idx) : pe.self_dmin(idx); },
+                                                  !CLOSEST_S && from_s);
       if (done) {
         if (from_s) ps.store(idx, w.result(), w.hit_prim >= 0);
         else pe.store(idx, w.result(), w.hit_prim >= 0);
@@ -917,6 +1041,19 @@ __global__ void k_generate_primary(FrameParams fp, const double *__restrict__ sx
   }
 }
 
+// hit distances of traced camera rays (ptamd_trace_primary): the walk names the primitive, the
+// reference's test gives its t
+__global__ void k_primary_t(DevScene S, RayQ q, const int32_t *__restrict__ prim, uint32_t n, double min_t,
+                            double *__restrict__ t_out) {
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) {
+    double t = -1.0, u, v;
+    if (prim[k] >= 0)
+      exact_test(S, prim[k], V(q.o[0][k], q.o[1][k], q.o[2][k]), V(q.d[0][k], q.d[1][k], q.d[2][k]), min_t, t, u, v);
+    t_out[k] = t;
+  }
+}
+
 // Ray and vertex records live at FIXED positions (a bounce ray at its parent's
 // list position, light sample q of vertex i at slot i*nls + q) and the queues are
 // ordered index lists built by ballot / prefix-sum compaction: no atomics, and
@@ -927,10 +1064,13 @@ struct ExtendPolicy {
   const int32_t *list;
   HitBuf hb;
   double min_t, max_t;
+  const int32_t *self_code;  // VertexBuf::self_code / self_dmin: a bounce ray sits at its vertex's entry
+  const float *dmin;
   __device__ __forceinline__ double min_t_all() const { return min_t; }
   // false: the slot holds no ray (see k_generate); its hit record says so
-  __device__ __forceinline__ bool load(uint32_t i, v3 &o, v3 &d, double &tmax) const {
+  __device__ __forceinline__ bool load(uint32_t i, v3 &o, v3 &d, double &tmax, int32_t &self) const {
     const uint32_t j = list ? (uint32_t)list[i] : i;
+    self = list ? self_code[j] : CHILD_EMPTY;  // camera rays start on nothing
     d = V(q.d[0][j], q.d[1][j], q.d[2][j]);
     if (!list && d.x == 0 && d.y == 0 && d.z == 0) {
       hb.prim[i] = PRIM_UNUSED;
@@ -940,29 +1080,25 @@ struct ExtendPolicy {
     tmax = max_t;
     return true;
   }
-  __device__ __forceinline__ void record(uint32_t i, double u, double v) const {
-    hb.u[i] = u;
-    hb.v[i] = v;
-  }
-  // (u, v of the hit are in place already; without a hit nobody reads them)
-  __device__ __forceinline__ void store(uint32_t i, const Hit &h, bool) const {
-    hb.prim[i] = h.prim;
-    hb.t[i] = h.t;
-  }
+  __device__ __forceinline__ double ray_end(uint32_t) const { return max_t; }
+  __device__ __forceinline__ float self_dmin(uint32_t i) const { return dmin[list[i]]; }
+  // (the hit's t, u, v are computed by the kernel that shades it)
+  __device__ __forceinline__ void store(uint32_t i, const Hit &h, bool) const { hb.prim[i] = h.prim; }
 };
 
 template <bool COUNT>
 __global__ void TRAV_BOUNDS_N(PTAMD_WAVES_EXTEND)
     k_extend(DevScene S, RayQ q, const int32_t *__restrict__ list, HitBuf hb, Ctl *ctl, double min_t, double max_t,
-             uint2 *gstack) {
+             uint2 *gstack, const int32_t *__restrict__ self_code, const float *__restrict__ self_dmin) {
   extern __shared__ uint2 lds_stack[];
   const TravStack stack{(lds_uint2 *)lds_stack, gstack, gridDim.x * blockDim.x, blockIdx.x * blockDim.x + threadIdx.x, PTAMD_STACK_EXTEND};
-  uint32_t cn = 0, ct = 0;
-  const ExtendPolicy pol{q, list, hb, min_t, max_t};
-  trace_rays<0, COUNT, PTAMD_REFILL_EXTEND>(S, pol, ctl->n_cur, &ctl->grab[0], stack, cn, ct);
+  uint32_t cn = 0, ct = 0, cx = 0;
+  const ExtendPolicy pol{q, list, hb, min_t, max_t, self_code, self_dmin};
+  trace_rays<0, COUNT, PTAMD_REFILL_EXTEND>(S, pol, ctl->n_cur, &ctl->grab[0], stack, cn, ct, cx);
   if (COUNT) {
     atomicAdd(&ctl->st_nodes, (unsigned long long)cn);
     atomicAdd(&ctl->st_tests, (unsigned long long)ct);
+    atomicAdd(&ctl->st_exact, (unsigned long long)cx);
   }
 }
 
@@ -976,20 +1112,26 @@ struct ShadowPolicy {
   VertexBuf vb;
   FastDiv by_nls;  // slot -> entry (exact for slot < 2^31, nls < 2^16: both enforced by ptamd_trace_list)
   __device__ __forceinline__ double min_t_all() const { return PT_EPS_D; }
-  __device__ __forceinline__ bool load(uint32_t i, v3 &o, v3 &d, double &tmax) const {
+  __device__ __forceinline__ bool load(uint32_t i, v3 &o, v3 &d, double &tmax, int32_t &self) const {
     const int32_t slot = sq.slot[i];
     const uint32_t e = by_nls.div((uint32_t)slot);
+    self = vb.self_code[e];
     o = V(vb.hp[0][e], vb.hp[1][e], vb.hp[2][e]);
     const SRay r = sq.ray[slot];
     d = V(r.d[0], r.d[1], r.d[2]);
     tmax = HEMI ? (double)INFINITY : r.max_t;
     return true;
   }
-  __device__ __forceinline__ void record(uint32_t, double, double) const {}
+  __device__ __forceinline__ double ray_end(uint32_t i) const {
+    return HEMI ? (double)INFINITY : sq.ray[sq.slot[i]].max_t;
+  }
+  __device__ __forceinline__ float self_dmin(uint32_t i) const { return vb.self_dmin[by_nls.div((uint32_t)sq.slot[i])]; }
   __device__ __forceinline__ void store(uint32_t i, const Hit &h, bool found) const {
     const int32_t slot = sq.slot[i];
     if (!HEMI) {
-      vb.vis[slot] = found ? 0 : 1;
+      // 3: one primitive is left to decide (k_resolve)
+      vb.vis[slot] = found ? (h.certain ? 0 : 3) : 1;
+      if (found && !h.certain) vb.pend_prim[slot] = h.prim;
     } else {
       if (found) {
         const int32_t m = S.prim_info[h.prim] >> 1;
@@ -1011,13 +1153,14 @@ __global__ void TRAV_BOUNDS_N(PTAMD_WAVES_SHADOW)
     k_shadow(DevScene S, ShadowQ sq, VertexBuf vb, Ctl *ctl, FastDiv by_nls, uint2 *gstack) {
   extern __shared__ uint2 lds_stack[];
   const TravStack stack{(lds_uint2 *)lds_stack, gstack, gridDim.x * blockDim.x, blockIdx.x * blockDim.x + threadIdx.x, PTAMD_STACK_SHADOW};
-  uint32_t cn = 0, ct = 0;
+  uint32_t cn = 0, ct = 0, cx = 0;
   const ShadowPolicy<HEMI> pol{S, sq, vb, by_nls};
-  if (HEMI) trace_rays<0, COUNT, PTAMD_REFILL_SHADOW>(S, pol, ctl->n_shadow, &ctl->grab[1], stack, cn, ct);
-  else trace_rays<1, COUNT, PTAMD_REFILL_SHADOW>(S, pol, ctl->n_shadow, &ctl->grab[1], stack, cn, ct);
+  if (HEMI) trace_rays<0, COUNT, PTAMD_REFILL_SHADOW>(S, pol, ctl->n_shadow, &ctl->grab[1], stack, cn, ct, cx);
+  else trace_rays<1, COUNT, PTAMD_REFILL_SHADOW>(S, pol, ctl->n_shadow, &ctl->grab[1], stack, cn, ct, cx);
   if (COUNT) {
     atomicAdd(&ctl->st_nodes, (unsigned long long)cn);
     atomicAdd(&ctl->st_tests, (unsigned long long)ct);
+    atomicAdd(&ctl->st_exact, (unsigned long long)cx);
   }
 }
 
@@ -1029,8 +1172,8 @@ __global__ void TRAV_BOUNDS_N(PTAMD_WAVES_EXTEND)
              FastDiv by_nls, uint2 *gstack) {
   extern __shared__ uint2 lds_stack[];
   const TravStack stack{(lds_uint2 *)lds_stack, gstack, gridDim.x * blockDim.x, blockIdx.x * blockDim.x + threadIdx.x, PTAMD_STACK_EXTEND};
-  uint32_t cn = 0, ct = 0;
-  const ExtendPolicy pe{q, list, hb, PT_EPS_D, (double)INFINITY};
+  uint32_t cn = 0, ct = 0, cx = 0;
+  const ExtendPolicy pe{q, list, hb, PT_EPS_D, (double)INFINITY, vb.self_code, vb.self_dmin};
   for (int k = 0; k < 3; k++) vb.hp[k] = q.o[k];  // the same arrays (see ptamd_trace_list): one set of pointers to hold
   const ShadowPolicy<HEMI> ps{S, sq, vb, by_nls};
   const uint32_t n_e = ctl->n_next, n_s = ctl->n_shadow;
@@ -1038,10 +1181,11 @@ __global__ void TRAV_BOUNDS_N(PTAMD_WAVES_EXTEND)
     ctl->st_two_ext += n_e;
     ctl->st_two_shadow += n_s;
   }
-  trace_two_lists<HEMI, COUNT, PTAMD_REFILL_EXTEND>(S, pe, n_e, &ctl->grab[2], ps, n_s, &ctl->grab[1], stack, cn, ct);
+  trace_two_lists<HEMI, COUNT, PTAMD_REFILL_EXTEND>(S, pe, n_e, &ctl->grab[2], ps, n_s, &ctl->grab[1], stack, cn, ct, cx);
   if (COUNT) {
     atomicAdd(&ctl->st_nodes, (unsigned long long)cn);
     atomicAdd(&ctl->st_tests, (unsigned long long)ct);
+    atomicAdd(&ctl->st_exact, (unsigned long long)cx);
   }
 }
 
@@ -1166,10 +1310,11 @@ __global__ void __launch_bounds__(256)
         const int32_t kind = S.mat_kind[mat];
         const v3 ro = V(q.o[0][j], q.o[1][j], q.o[2][j]);
         const v3 rd = V(q.d[0][j], q.d[1][j], q.d[2][j]);
-        const double t = hb.t[i];
+        // the walk only names the primitive: its t, u, v as the reference computes them
+        double t, u, v;
+        exact_test(S, prim, ro, rd, depth == 1 ? fp.n_clip : PT_EPS_D, t, u, v);
         if (!(info & 1)) {
           // (1 - u - v) * n1 + u * n2 + v * n3, src/scene/triangle.cpp:66
-          const double u = hb.u[i], v = hb.v[i];
           const double *N = S.prim_nrm + (size_t)prim * 9;
           n_sh = vadd(vadd(vscale(V(N[0], N[1], N[2]), 1 - u - v), vscale(V(N[3], N[4], N[5]), u)),
                       vscale(V(N[6], N[7], N[8]), v));
@@ -1243,7 +1388,27 @@ __global__ void __launch_bounds__(256)
         }
         vb.flag[i] = flag;
         // the hit point: origin of the vertex's shadow rays and of its bounce ray (vb.hp IS qn.o)
-        if (flag || push) { vb.hp[0][i] = hit_p.x; vb.hp[1][i] = hit_p.y; vb.hp[2][i] = hit_p.z; }
+        if (flag || push) {
+          vb.hp[0][i] = hit_p.x; vb.hp[1][i] = hit_p.y; vb.hp[2][i] = hit_p.z;
+          // Every ray that leaves this vertex meets the vertex's own triangle at t = T / D with
+          // T = ((o - p1) x e1) . e2, a number that depends on the origin only and is zero up to
+          // FP64 rounding; the reference rejects it through its min_t clause unless the ray
+          // grazes the triangle (|D| tiny). T is computed here as Triangle::test computes it
+          // (src/scene/triangle.cpp:33-36), and the walks get the |D| above which |T / D| is
+          // certainly below min_t (prim32.h, classify_tri32: dmin).
+          int32_t self = CHILD_EMPTY;
+          float dmin = INFINITY;
+          if (!(info & 1)) {
+            const double *P = S.prim + (size_t)prim * PRIM_STRIDE;
+            const v3 sv = vsub(hit_p, V(P[0], P[1], P[2]));
+            const double Tn = vdot(vcross(sv, V(P[3], P[4], P[5])), V(P[6], P[7], P[8]));
+            const float tu = fmaxf(f_up(fabs(Tn)), 7.888609052210118e-31f /* 2^-100 */);
+            dmin = (tu * 1.002f) / f_down(PT_EPS_D);
+            self = ~prim;
+          }
+          vb.self_code[i] = self;
+          vb.self_dmin[i] = dmin;
+        }
       }
       cp.pflag[i] = push ? 1 : 0;
     }
@@ -1406,8 +1571,19 @@ __global__ void __launch_bounds__(256)
 
 // L_out = sum of the unoccluded samples in sampling order, then / sample_count
 // (pathtracer.cpp:116-134, 85); the path gains T * L_out.
-__global__ void k_resolve(FrameParams fp, RayQ q, const int32_t *__restrict__ list, VertexBuf vb, PathBuf pb, Ctl *ctl,
-                          int32_t depth) {
+// (A shadow ray whose walk left one primitive undecided, vis = 3, is settled here by the
+// reference's FP64 test of that primitive: bvh.cpp:187, occluded when it is hit strictly before
+// the ray's end.)
+__device__ __forceinline__ bool pending_visible(const DevScene &S, const VertexBuf &vb, const SRay *rays, uint32_t i,
+                                                size_t slot) {
+  const SRay r = rays[slot];
+  double t, u, v;
+  const bool ok = exact_test(S, vb.pend_prim[slot], V(vb.hp[0][i], vb.hp[1][i], vb.hp[2][i]), V(r.d[0], r.d[1], r.d[2]),
+                             PT_EPS_D, t, u, v);
+  return !(ok && t < r.max_t);
+}
+__global__ void k_resolve(FrameParams fp, DevScene S, RayQ q, const int32_t *__restrict__ list, VertexBuf vb,
+                          const SRay *__restrict__ rays, PathBuf pb, Ctl *ctl, int32_t depth) {
   const uint32_t n = ctl->n_cur;
   const uint32_t stride = gridDim.x * blockDim.x;
   const int nls = fp.nls;
@@ -1432,12 +1608,16 @@ __global__ void k_resolve(FrameParams fp, RayQ q, const int32_t *__restrict__ li
 #pragma unroll
             for (int qq = 0; qq < 4; qq++) cc[qq] = vb.contrib[b + q4 + qq];  // whether visible or not
 #pragma unroll
-            for (int qq = 0; qq < 4; qq++)
-              if (((vw >> (8 * qq)) & 0xffu) == 1u) L = vadd(L, V(cc[qq].c[0], cc[qq].c[1], cc[qq].c[2]));
+            for (int qq = 0; qq < 4; qq++) {
+              const uint32_t vs = (vw >> (8 * qq)) & 0xffu;
+              if (vs == 1u || (vs == 3u && pending_visible(S, vb, rays, i, b + q4 + qq)))
+                L = vadd(L, V(cc[qq].c[0], cc[qq].c[1], cc[qq].c[2]));
+            }
           }
         } else {
           for (int qq = 0; qq < nls; qq++) {
-            if (vb.vis[b + qq] == 1) {
+            const uint32_t vs = vb.vis[b + qq];
+            if (vs == 1u || (vs == 3u && pending_visible(S, vb, rays, i, b + qq))) {
               const Contrib cc = vb.contrib[b + qq];
               L = vadd(L, V(cc.c[0], cc.c[1], cc.c[2]));
             }
@@ -1688,6 +1868,7 @@ struct ptamd_context {
   Ctl *ctl = nullptr;
   uint32_t *block_count = nullptr;
   size_t block_count_cap = 0;
+  double scene_max_coord = 0;
   uint32_t *static_block_count = nullptr;  // this GPU's copy of `scratch` (ptamd_filter_list_static)
   uint2 *gstack = nullptr;  // overflow levels of the per-lane traversal stacks
   size_t gstack_bytes = 0;
@@ -1784,12 +1965,15 @@ int ensure_buffers(ptamd_context *c, int64_t paths, int nls, bool pend) {
     for (int j = 1; j < 10; j++) off_q[k][j] = take(P * 8);
   }
   off_hit[0] = take(P * 4);
-  for (int j = 1; j < 4; j++) off_hit[j] = take(P * 8);
+  off_hit[1] = take(P * 8);
+  off_hit[2] = take(P * 4);
+  off_hit[3] = take(P * 4);
   off_sq[0] = take(PN * 4);
   off_sq[1] = take(PN * sizeof(SRay));
   off_vb[3] = take(P);
   off_vb[4] = take(PN * sizeof(Contrib));
   off_vb[7] = take(PN + 4);
+  off_vb[5] = take(PN * 4);
   for (int j = 0; j < 6; j++) off_pb[j] = take(P * 8);
   for (int k = 0; k < 2; k++) off_list[k] = take(P * 4);
   off_cp[0] = take(P);
@@ -1807,8 +1991,9 @@ int ensure_buffers(ptamd_context *c, int64_t paths, int nls, bool pend) {
   }
   c->hb.prim = (int32_t *)(b + off_hit[0]);
   c->hb.t = (double *)(b + off_hit[1]);
-  c->hb.u = (double *)(b + off_hit[2]);
-  c->hb.v = (double *)(b + off_hit[3]);
+  c->vb.self_code = (int32_t *)(b + off_hit[2]);
+  c->vb.self_dmin = (float *)(b + off_hit[3]);
+  c->vb.pend_prim = (int32_t *)(b + off_vb[5]);
   c->sq.slot = (int32_t *)(b + off_sq[0]);
   c->sq.ray = (SRay *)(b + off_sq[1]);
   for (int j = 0; j < 3; j++) c->vb.hp[j] = nullptr;  // set per depth: the next ray queue's origin arrays
@@ -1978,7 +2163,11 @@ static bool quantize_node(DevNode &n, const double boxes[][6], int nk) {
       if (!ok || (double)(float)org != org) continue;
       n.org[a] = (float)org;
       n.exps |= (uint32_t)(uint8_t)(int8_t)e << (8 * a);
-      for (int k = 0; k < nk; k++) { n.q[k][a] = q[k][0]; n.q[k][3 + a] = q[k][1]; }
+      n.qlo[a] = n.qhi[a] = 0;
+      for (int k = 0; k < nk; k++) {
+        n.qlo[a] |= (uint32_t)q[k][0] << (8 * k);
+        n.qhi[a] |= (uint32_t)q[k][1] << (8 * k);
+      }
       break;
     }
   }
@@ -2144,6 +2333,9 @@ int ptamd_upload_scene(ptamd_context *c, const ptamd_scene_desc *d) {
   // ---- primitive records in visiting order
   std::vector<double> prim((size_t)NP * PRIM_STRIDE, 0.0), nrm((size_t)NP * 9);
   std::vector<int32_t> info(NP);
+  std::vector<uint4> prim32((size_t)NP * 3);
+  bool coords_ok = true;
+  double max_coord = 0;
   for (int i = 0; i < NP; i++) {
     const int p = visit_order[i];
     const double *P = d->prim_pos + 9 * (size_t)p;
@@ -2161,6 +2353,29 @@ int ptamd_upload_scene(ptamd_context *c, const ptamd_scene_desc *d) {
     }
     memcpy(R + 9, &info[i], 4);
     memcpy(nrm.data() + (size_t)i * 9, d->prim_nrm + 9 * (size_t)p, 72);
+    // the FP32 pre-test's record
+    unsigned char *Q = reinterpret_cast<unsigned char *>(prim32.data() + (size_t)i * 3);
+    memcpy(Q, R, 24);
+    float ef[6];
+    if (d->prim_type[p] == PTAMD_PRIM_TRIANGLE) {
+      for (int k = 0; k < 6; k++) ef[k] = (float)R[3 + k];
+    } else {
+      ef[0] = NAN;
+      ef[1] = (float)R[3];
+      for (int k = 2; k < 6; k++) ef[k] = 0.f;
+    }
+    memcpy(Q + 24, ef, 24);
+    // prim32.h assumes coordinates (and so edge lengths) well inside the float range
+    if (d->prim_type[p] == PTAMD_PRIM_TRIANGLE) {
+      for (int k = 0; k < 9; k++) max_coord = std::max(max_coord, std::fabs(P[k]));
+    } else {
+      for (int k = 0; k < 3; k++) max_coord = std::max(max_coord, std::fabs(P[k]) + std::fabs(P[3]));
+    }
+  }
+  coords_ok = max_coord < 1048576.0;  // also false for NaN
+  if (!coords_ok) {
+    ptamd::set_error("scene coordinates of 2^20 or more are not supported");
+    return PTAMD_ERR_SCENE;
   }
   free_scene(c);
   c->dev2ref = visit_order;
@@ -2169,6 +2384,7 @@ int ptamd_upload_scene(ptamd_context *c, const ptamd_scene_desc *d) {
   int rc;
   if ((rc = upload(c, nodes, &S.nodes))) return rc;
   if ((rc = upload(c, prim, &S.prim))) return rc;
+  if ((rc = upload(c, prim32, &S.prim32))) return rc;
   if ((rc = upload(c, info, &S.prim_info))) return rc;
   if ((rc = upload(c, nrm, &S.prim_nrm))) return rc;
   std::vector<int32_t> mk(d->mat_kind, d->mat_kind + d->n_materials);
@@ -2187,6 +2403,12 @@ int ptamd_upload_scene(ptamd_context *c, const ptamd_scene_desc *d) {
   S.n_lights = d->n_lights;
   S.jitter_n = d->jitter_n;
   S.root_code = root_code;
+  c->scene_max_coord = max_coord;
+  {
+    double far = max_coord;  // camera rays start at the camera, every other ray on a primitive
+    if (c->have_camera) for (int k = 0; k < 3; k++) far = std::max(far, std::fabs(c->cam.pos[k]));
+    S.coord_bound = (float)(1.01 * far + 1e-30);
+  }
   S.stack_cap = max_depth + 1;
   c->S = S;
   c->have_scene = true;
@@ -2197,6 +2419,9 @@ int ptamd_upload_scene(ptamd_context *c, const ptamd_scene_desc *d) {
 int ptamd_set_camera(ptamd_context *c, const ptamd_camera *cam) {
   if (!c || !cam) { ptamd::set_error("null argument"); return PTAMD_ERR_ARG; }
   c->cam = *cam;
+  // camera rays start at the camera, every other ray on a primitive
+  const double far = std::max(c->scene_max_coord, std::max(std::fabs(cam->pos[0]), std::max(std::fabs(cam->pos[1]), std::fabs(cam->pos[2]))));
+  c->S.coord_bound = (float)(1.01 * far + 1e-30);
   c->have_camera = true;
   return PTAMD_OK;
 }
@@ -2331,8 +2556,8 @@ int ptamd_trace_list(ptamd_context *c, const ptamd_pixel_list *list, int32_t sam
       const int32_t *lst = depth == 1 ? nullptr : c->list[cur];
       if (!traced_ahead) {
         L.begin(PTAMD_K_EXTEND);
-        if (c->prof_counters) hipLaunchKernelGGL((k_extend<true>), egrid, tblock, elds, s, c->S, c->q[cur], lst, c->hb, c->ctl, min_t, max_t, gstack);
-        else hipLaunchKernelGGL((k_extend<false>), egrid, tblock, elds, s, c->S, c->q[cur], lst, c->hb, c->ctl, min_t, max_t, gstack);
+        if (c->prof_counters) hipLaunchKernelGGL((k_extend<true>), egrid, tblock, elds, s, c->S, c->q[cur], lst, c->hb, c->ctl, min_t, max_t, gstack, (const int32_t *)c->vb.self_code, (const float *)c->vb.self_dmin);
+        else hipLaunchKernelGGL((k_extend<false>), egrid, tblock, elds, s, c->S, c->q[cur], lst, c->hb, c->ctl, min_t, max_t, gstack, (const int32_t *)c->vb.self_code, (const float *)c->vb.self_dmin);
         L.end();
       }
       traced_ahead = false;
@@ -2374,7 +2599,7 @@ int ptamd_trace_list(ptamd_context *c, const ptamd_pixel_list *list, int32_t sam
           L.end();
         }
         L.begin(PTAMD_K_RESOLVE);
-        hipLaunchKernelGGL(k_resolve, ggrid, 256, 0, s, fp, c->q[cur], lst, vb, pb, c->ctl, depth);
+        hipLaunchKernelGGL(k_resolve, ggrid, 256, 0, s, fp, c->S, c->q[cur], lst, vb, (const SRay *)c->sq.ray, pb, c->ctl, depth);
         hipLaunchKernelGGL(k_advance, 1, 1, 0, s, c->ctl);
         L.end();
       } else {
@@ -2536,6 +2761,7 @@ int ptamd_get_stats(ptamd_context *c, ptamd_stats *out) {
     c->stats.path_vertices = h.st_vertices;
     c->stats.nodes_visited = h.st_nodes;
     c->stats.prim_tests = h.st_tests;
+    c->stats.exact_tests = h.st_exact;
     c->stats.samples = h.st_samples;
     c->stats.two_ext_rays = h.st_two_ext;
     c->stats.two_shadow_rays = h.st_two_shadow;
@@ -2659,7 +2885,8 @@ int ptamd_trace_primary(ptamd_context *c, int64_t n, const double *sx, const dou
     HIPCHK(hipMemcpyAsync(d_sy, sy + b, m * sizeof(double), hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_set_counts, 1, 1, 0, s, c->ctl, PixView{nullptr, nullptr, (long long)m, 0u, 1u}, 0u, (uint32_t)m, 1u);
     hipLaunchKernelGGL(k_generate_primary, grid_for(c, 4), 256, 0, s, fp, d_sx, d_sy, (uint32_t)m, c->q[0]);
-    hipLaunchKernelGGL((k_extend<false>), tgrid, tblock, lds, s, c->S, c->q[0], (const int32_t *)nullptr, c->hb, c->ctl, fp.n_clip, fp.f_clip, tl.gstack);
+    hipLaunchKernelGGL((k_extend<false>), tgrid, tblock, lds, s, c->S, c->q[0], (const int32_t *)nullptr, c->hb, c->ctl, fp.n_clip, fp.f_clip, tl.gstack, (const int32_t *)nullptr, (const float *)nullptr);
+    hipLaunchKernelGGL(k_primary_t, grid_for(c, 4), 256, 0, s, c->S, c->q[0], (const int32_t *)c->hb.prim, (uint32_t)m, fp.n_clip, c->hb.t);
     HIPCHK(hipMemcpyAsync(prim.data(), c->hb.prim, m * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(t_out + b, c->hb.t, m * sizeof(double), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));

@@ -11,10 +11,15 @@ reference's defaults). samples = sum of per-pixel sample counts, as the referenc
 sampleCountBuffer would hold them. Rank 0 prints ONE JSON line.
 
 The line also carries
-  roofline      for the dominant kernel: algorithmic bytes of its rays (per-ray
-                node visits and primitive tests counted by the CPU restatement of
-                the reference's traversal on a sample of the same workload) over
-                its HIP-event time, against the 8 TB/s HBM peak;
+  roofline      for the dominant kernel (a BVH walk: bound by VALU instruction issue,
+                not by HBM). Top level: the issue ceiling, lane-operations per second
+                against 1024 SIMDs x 16 lanes x 2.4 GHz, from the committed rocprofv3
+                counter passes of this workload and the kernel's live HIP-event time.
+                Beside it: `hbm_algorithmic` (bytes the REFERENCE's traversal would
+                move for the same rays, counted by the CPU restatement, over the live
+                kernel time against 8 TB/s: above 1, the GPU walk does far less work per
+                ray), `hbm_measured` (FETCH_SIZE / WRITE_SIZE counters), `l2_walk` (the
+                GPU walk's own node and primitive fetches against the L2 peak);
   cpu_baseline  the reference's own renderer (its sources, built by
                 `make -C oracle ref`) timed on this host on a bounded cell of the
                 same frame.
@@ -32,6 +37,10 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
+L2_PEAK_GBS = 34500.0  # aggregate of the eight XCDs' L2s
+# VALU issue ceiling: 256 CUs x 4 SIMDs x 16 lanes, one lane-operation per lane and cycle at 2.4 GHz
+N_SIMD, SIMD_LANES, CLOCK_HZ = 1024, 16, 2.4e9
+LANE_OPS_PEAK_T = N_SIMD * SIMD_LANES * CLOCK_HZ / 1e12
 
 
 def parse_args():
@@ -50,7 +59,8 @@ def parse_args():
     ap.add_argument("--depth", type=int, default=5)
     ap.add_argument("--max-paths", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-spp", type=int, default=256)
+    ap.add_argument("--cpu-spp", type=int, default=0, help="samples per pixel of the CPU baseline's cell (0: the workload's own)")
+    ap.add_argument("--cpu-cell", type=int, default=8, help="width in pixels of the CPU baseline's cell (full frame height)")
     ap.add_argument("--target-paths", type=int, default=16 << 20, help="see PixelSchedule.batches")
     ap.add_argument("--max-batches", type=int, default=32)
     ap.add_argument("--per-pixel", type=int, default=0,
@@ -69,7 +79,8 @@ def resolve_scene(name, rank):
         path = make_standin_scene.standin_path("dragon")
         if rank == 0:
             make_standin_scene.ensure("dragon")
-        return path, "CBdragon stand-in (CBempty box + 100k-triangle procedural knot; CBdragon.dae is absent from the reference checkout)", 1024
+        return path, ("CBdragon stand-in (CBempty box with the CB scenes' area light + 100k-triangle procedural knot; "
+                      "CBdragon.dae is absent from the reference checkout)"), 1024
     if name == "bunny":
         return os.path.join(ROOT, "scenes", "CBbunny.dae"), "CBbunny.dae", 256
     if name == "spheres":
@@ -84,16 +95,17 @@ def cpu_leg(scene_path, args, spp, threads_port):
     from pathtracer_amd import cabi, ptar
     import oracle_lib as O
     w, h = args.width, args.height
-    cw = 32
+    cw = max(1, min(args.cpu_cell, w))
     cx = w // 2 - cw // 2
+    cpu_spp = args.cpu_spp or spp
     sample = "cell x=%d..%d, y=0..%d of the %dx%d frame at %d spp (-l %d -m %d, adaptive 32/0.05)" % (
-        cx, cx + cw, h, w, h, args.cpu_spp, args.light_samples, args.depth)
-    out = {"sample": sample}
+        cx, cx + cw, h, w, h, cpu_spp, args.light_samples, args.depth)
+    out = {"sample": sample, "host": host_description()}
     # the CPU restatement: counts the reference traversal's node visits / primitive tests
     sc = pt.Scene(scene_path)
     arr = sc.arrays()
     cam = sc.camera(w, h)
-    p = cabi.make_params(w, h, ns_aa=args.cpu_spp, max_ray_depth=args.depth, ns_area_light=args.light_samples,
+    p = cabi.make_params(w, h, ns_aa=cpu_spp, max_ray_depth=args.depth, ns_area_light=args.light_samples,
                          rect=(cx, 0, cx + cw, h), specular=args.specular)
     _, _, st = O.render(arr, cam, p, threads=threads_port)
     ext_rays = st.rays - st.shadow_rays
@@ -113,7 +125,7 @@ def cpu_leg(scene_path, args, spp, threads_port):
         tmp = os.path.join(ROOT, "gpurun_out", "bench_ref_cell.ptar")
         os.makedirs(os.path.dirname(tmp), exist_ok=True)
         threads_ref = 8  # the thread count of the reference's own benchmark command line
-        cmd = [ref, "render", "-s", str(args.cpu_spp), "-l", str(args.light_samples), "-m", str(args.depth),
+        cmd = [ref, "render", "-s", str(cpu_spp), "-l", str(args.light_samples), "-m", str(args.depth),
                "-t", str(threads_ref), "-r", str(w), str(h), "-p", str(cx), "0", str(cw), str(h), "-f", tmp, scene_path]
         r = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900)
         if r.returncode == 0:
@@ -122,12 +134,61 @@ def cpu_leg(scene_path, args, spp, threads_port):
     return out
 
 
+def host_description():
+    """CPU model and core counts of this host (the CPU baseline's machine)."""
+    model = None
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name"):
+                    model = ln.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count()
+    return {"cpu_model": model, "logical_cpus": os.cpu_count(), "cpus_usable_by_this_process": usable}
+
+
+KERNEL_NAMES = {"extend": "k_extend<false>", "shadow": "k_shadow<false, false>", "shade": "k_shade<false>",
+                "resolve": "k_resolve", "trace2": "k_trace2<false, false>"}
+
+
+def profiled_counters(scene, kernel):
+    """Per-launch counter sums of `kernel` from the committed rocprofv3 passes of this workload
+    (profiles/r*_<scene>_summary.json, written by tools/profile_round.sh): VALU lane-operations
+    (SQ_THREAD_CYCLES_VALU: one count per active lane and VALU instruction), VALU instructions,
+    cycles the SIMDs spent issuing them (SQ_ACTIVE_INST_VALU x 4), L2 requests, and the kernel's
+    duration in that profile's kernel trace."""
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_summary.json" % scene)))
+    if kernel not in KERNEL_NAMES or not found:
+        return None
+    path = found[-1]
+    try:
+        d = json.load(open(path))
+        k = KERNEL_NAMES[kernel]
+        sq, sq2, grbm, l1 = d["pmc_sq"][k], d["pmc_sq2"][k], d["pmc_grbm"][k], d["pmc_l1"][k]
+        n = sq2["_dispatches"]
+        return {"source": os.path.relpath(path, ROOT), "launches": n,
+                "lane_ops_per_launch": sq2["SQ_THREAD_CYCLES_VALU"] / n,
+                "valu_insts_per_launch": sq["SQ_INSTS_VALU"] / sq["_dispatches"],
+                "valu_issue_cycles_per_launch": 4.0 * sq["SQ_ACTIVE_INST_VALU"] / sq["_dispatches"],
+                "gpu_cycles_per_launch": grbm["GRBM_GUI_ACTIVE"] / 8.0 / grbm["_dispatches"],
+                "l2_read_requests_per_launch": l1["TCP_TCC_READ_REQ_sum"] / l1["_dispatches"],
+                "trace_avg_launch_ms": d["kernels"][k]["avg_us"] / 1e3,
+                "l2_hit": d["pmc_l2"][k]["TCC_HIT_sum"] / max(d["pmc_l2"][k]["TCC_HIT_sum"] + d["pmc_l2"][k]["TCC_MISS_sum"], 1)}
+    except Exception:
+        return None
+
+
 def profiled_traffic(scene, kernel):
     """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this
     workload (profiles/, separate FETCH_SIZE and WRITE_SIZE runs). FETCH_SIZE is in KiB and,
     on gfx950, counts 128-byte read requests as 64 bytes, hence the factor 2."""
-    names = {"extend": "k_extend<false>", "shadow": "k_shadow<false, false>", "shade": "k_shade<false>",
-             "resolve": "k_resolve", "trace2": "k_trace2<false, false>"}
+    names = KERNEL_NAMES
     import glob
     found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_summary.json" % scene)))
     if kernel not in names or not found:
@@ -279,48 +340,85 @@ def main():
                 sc_ = dev.stats()
                 if sc_.rays:
                     own = {"nodes_per_ray": sc_.nodes_visited / 4.0 / sc_.rays, "prims_per_ray": sc_.prim_tests / sc_.rays}
-                    # its records: 64-byte 4-wide node, 80-byte primitive, the same 92 bytes of ray and hit
-                    own["bytes_per_ray"] = 64 * own["nodes_per_ray"] + 80 * own["prims_per_ray"] + 92
+                    own["fp64_tests_per_prim_test"] = sc_.exact_tests / max(sc_.prim_tests, 1)
+                    # its records: 64-byte 4-wide node, 48-byte primitive (80 more when the FP32 test is
+                    # undecided), the same 92 bytes of ray and hit
+                    own["bytes_per_ray"] = (64 * own["nodes_per_ray"] + (48 + 80 * own["fp64_tests_per_prim_test"]) * own["prims_per_ray"] + 92)
             except Exception as e:
                 own = {"error": repr(e)}
         # ---- roofline of the dominant kernel (rank 0's launches)
         names = cabi.K_NAMES
         if not args.warmup:
             dom = max(range(NK), key=lambda k: agg["ms"][k])
-        roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
+        roof = {"bound": None, "achieved": None, "peak": None, "unit": None, "frac": None,
                 "traffic": None, "kernel": names[dom],
                 "kernel_ms": {names[k]: agg["ms"][k] for k in range(NK) if agg["ms"][k]},
                 "launches": {names[k]: agg["launches"][k] for k in range(NK) if agg["launches"][k]},
                 "kernel_ms_all_classes_warmup_frame": warm_ms}
+        ms = agg["ms"][dom]
+        n_launch = max(agg["launches"][dom], 1)
+        roof["avg_launch_ms"] = ms / n_launch
+        ext_rays = agg["rays"] - agg["shadow"]
+        rays = None
+        if dom in (1, 3, cabi.K_TRACE2):
+            # rays the dominant traversal kernel traced: k_extend the bounce and camera rays that did
+            # not go through k_trace2, k_shadow likewise, k_trace2 rays of both kinds in one launch
+            if dom == 1:
+                rays = ext_rays - agg["two_ext"]
+            elif dom == 3:
+                rays = agg["shadow"] - agg["two_shadow"]
+            else:
+                rays = agg["two_ext"] + agg["two_shadow"]
+                roof["rays_per_launch_by_kind"] = {"bounce": agg["two_ext"] / n_launch, "shadow": agg["two_shadow"] / n_launch}
+            roof["rays_per_launch"] = rays / n_launch
+        standard = args.scene in ("dragon", "bunny") and (args.width, args.height) == (800, 600) and not args.specular
+        # ---- the binding ceiling of a BVH walk: VALU instruction issue. Lane-operations per launch come
+        # from the committed counter passes of this same command line, the time per launch is measured
+        # live (HIP events on the launch stream).
+        pc = profiled_counters(args.scene, names[dom]) if standard and args.pixel_stride == 1 else None
+        if pc and ms > 0:
+            t_launch = ms * 1e-3 / n_launch
+            ach = pc["lane_ops_per_launch"] / t_launch / 1e12
+            roof.update({"bound": "valu-issue", "achieved": ach, "peak": LANE_OPS_PEAK_T, "unit": "Tlane-op/s",
+                         "frac": ach / LANE_OPS_PEAK_T})
+            roof["issue"] = {
+                "definition": "VALU lane-operations (SQ_THREAD_CYCLES_VALU) per launch / live time per launch, against "
+                              "%d SIMDs x %d lanes x %.1f GHz" % (N_SIMD, SIMD_LANES, CLOCK_HZ / 1e9),
+                "lane_ops_per_launch": pc["lane_ops_per_launch"],
+                "lane_ops_per_ray": pc["lane_ops_per_launch"] / max(roof.get("rays_per_launch") or 1, 1),
+                "valu_insts_per_ray": 64.0 * pc["valu_insts_per_launch"] / max(roof.get("rays_per_launch") or 1, 1),
+                # of the cycles of all SIMDs during the profiled launch, the share that issued a VALU
+                # instruction, and of the 64 lanes of those instructions the share that was active
+                "simd_cycles_issuing_valu": pc["valu_issue_cycles_per_launch"] / (pc["gpu_cycles_per_launch"] * N_SIMD),
+                "lanes_active": pc["lane_ops_per_launch"] / (64.0 * pc["valu_insts_per_launch"]),
+                "profiled_avg_launch_ms": pc["trace_avg_launch_ms"], "source": pc["source"]}
+            roof["l2_measured"] = {"read_requests_per_launch": pc["l2_read_requests_per_launch"], "hit_rate": pc["l2_hit"],
+                                   "achieved_gbs_at_64B": pc["l2_read_requests_per_launch"] * 64 / t_launch / 1e9,
+                                   "peak": L2_PEAK_GBS}
+        if standard:
+            tr, src = profiled_traffic(args.scene, names[dom])
+            roof["traffic"], roof["traffic_source"] = tr, src
+            if tr and ms > 0:
+                g = tr / (ms * 1e-3 / n_launch) / 1e9
+                roof["hbm_measured"] = {"achieved": g, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": g / HBM_PEAK_GBS}
         if cpu and "counts" in cpu:
             c = cpu["counts"]
-            ext_rays = agg["rays"] - agg["shadow"]
             b_ext = 32 * c["V_ext"] + 36 * c["T_ext"] + 92
             b_sh = 32 * c["V_shadow"] + 36 * c["T_shadow"] + 92
-            if dom in (1, 3, cabi.K_TRACE2):
-                # rays the dominant traversal kernel traced: k_extend the bounce and camera rays that did
-                # not go through k_trace2, k_shadow likewise, k_trace2 rays of both kinds in one launch
+            if rays is not None and ms > 0:
                 if dom == 1:
-                    rays, b = ext_rays - agg["two_ext"], b_ext
+                    b = b_ext
                 elif dom == 3:
-                    rays, b = agg["shadow"] - agg["two_shadow"], b_sh
+                    b = b_sh
                 else:
-                    rays = agg["two_ext"] + agg["two_shadow"]
                     b = (agg["two_ext"] * b_ext + agg["two_shadow"] * b_sh) / max(rays, 1)
-                    roof["rays_per_launch_by_kind"] = {"bounce": agg["two_ext"] / max(agg["launches"][dom], 1),
-                                                       "shadow": agg["two_shadow"] / max(agg["launches"][dom], 1)}
-                ms = agg["ms"][dom]
-                ach = rays * b / (ms * 1e-3) / 1e9 if ms > 0 else None
-                roof.update({"achieved": ach, "frac": ach / HBM_PEAK_GBS if ach else None,
-                             "bytes_per_ray": b, "rays_per_launch": rays / max(agg["launches"][dom], 1),
-                             "algorithmic_bytes_per_launch": rays * b / max(agg["launches"][dom], 1),
-                             "avg_launch_ms": ms / max(agg["launches"][dom], 1)})
-                if own and "bytes_per_ray" in own and ach:
-                    # the same launches priced by what the GPU walk itself fetches (all rays averaged)
-                    own["achieved"] = ach * own["bytes_per_ray"] / b
-                    own["frac"] = own["achieved"] / HBM_PEAK_GBS
-                if args.scene in ("dragon", "bunny") and (args.width, args.height) == (800, 600):
-                    roof["traffic"], roof["traffic_source"] = profiled_traffic(args.scene, names[dom])
+                ach = rays * b / (ms * 1e-3) / 1e9
+                # the definition of the survey: bytes of the REFERENCE's traversal for these rays. Its
+                # fraction passes 1 because the GPU walk visits far fewer nodes; not a utilisation.
+                roof["hbm_algorithmic"] = {"achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                                           "bytes_per_ray": b, "algorithmic_bytes_per_launch": rays * b / n_launch}
+                if roof["bound"] is None:  # no counter passes for this workload: the survey's definition stands alone
+                    roof.update({"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS})
             # whole-frame figure: samples/s x algorithmic bytes per sample, the per-sample ray
             # and vertex counts being the reference traversal's (rays the GPU traced ahead of an
             # adaptive test and then dropped do not count)
@@ -330,15 +428,21 @@ def main():
             roof["frame_frac_of_hbm_peak"] = value * b_sample / 1e9 / (HBM_PEAK_GBS * world)
             roof["counts"] = c
         if own:
+            if "bytes_per_ray" in own and rays is not None and ms > 0:
+                # the same launches priced by what the GPU walk itself fetches, against the L2s that serve it
+                g = rays * own["bytes_per_ray"] / (ms * 1e-3) / 1e9
+                roof["l2_walk"] = {"achieved": g, "peak": L2_PEAK_GBS, "unit": "GB/s", "frac": g / L2_PEAK_GBS,
+                                   "bytes_per_ray": own["bytes_per_ray"]}
             roof["gpu_walk"] = own
         line["roofline"] = roof
         if cpu and "reference" in cpu:
             line["cpu_baseline"] = {"value": cpu["reference"]["value"], "unit": "samples/s",
                                     "cores": cpu["reference"]["cores"], "kind": "reference", "sample": cpu["sample"],
-                                    "port_value": cpu["port"]["value"], "port_cores": cpu["port"]["cores"]}
+                                    "port_value": cpu["port"]["value"], "port_cores": cpu["port"]["cores"],
+                                    "host": cpu["host"]}
         elif cpu and "port" in cpu:
             line["cpu_baseline"] = {"value": cpu["port"]["value"], "unit": "samples/s", "cores": cpu["port"]["cores"],
-                                    "kind": "port", "sample": cpu["sample"]}
+                                    "kind": "port", "sample": cpu["sample"], "host": cpu["host"]}
         elif cpu:
             line["cpu_baseline"] = cpu
         print(json.dumps(line), flush=True)

@@ -291,9 +291,6 @@ __device__ __forceinline__ RayF make_rayf(v3 d) {
 #ifndef PTAMD_GRID_MULT
 #define PTAMD_GRID_MULT 8
 #endif
-#ifndef PTAMD_TRIP
-#define PTAMD_TRIP 0
-#endif
 #ifndef PTAMD_NODE_STEPS
 #define PTAMD_NODE_STEPS 2
 #endif
@@ -618,30 +615,22 @@ struct Walk {
     return cur == CHILD_EMPTY;
   }
 
-  // One trip of an active lane; true when its walk is over. PTAMD_TRIP 0: PTAMD_NODE_STEPS box
-  // steps, then a primitive test for the lanes at a primitive (which includes lanes a box step
-  // has just brought there); 1: a primitive test after every box step.
+  // One trip of an active lane; true when its walk is over: PTAMD_NODE_STEPS box steps, then a
+  // primitive test for the lanes at a primitive (which includes lanes a box step has just brought
+  // there). Measured and rejected, with the FP32 primitive tests in place: a primitive test after
+  // every box step (4 to 9 % slower); putting off the second box step or the primitive test when
+  // fewer than 16 to 32 lanes want it (a step costs the wave the same however few lanes run it):
+  // within 1 % either way on CBbunny, 1 to 7 % slower on the 100k-triangle scene.
   template <int ANY, bool COUNT, class End, class Dmin>
   __device__ __forceinline__ bool trip(const DevScene &S, const TravStack &stack, uint32_t &n_nodes, uint32_t &n_tests,
                                        uint32_t &n_exact, float m0, double min_t, float min_lo, float min_hi,
                                        const End &ray_end, const Dmin &self_dmin, bool first_hit = false) {
-#if PTAMD_TRIP == 0
 #pragma unroll
     for (int k = 0; k < PTAMD_NODE_STEPS; k++)
       if (cur >= 0) node_step<COUNT>(S, stack, n_nodes, m0);
     if (cur == CHILD_EMPTY) return true;
     if (cur < 0) return prim_step<ANY, COUNT>(S, stack, n_tests, n_exact, min_t, min_lo, min_hi, ray_end, self_dmin, first_hit);
     return false;
-#else
-#pragma unroll
-    for (int k = 0; k < PTAMD_NODE_STEPS; k++) {
-      if (cur >= 0) node_step<COUNT>(S, stack, n_nodes, m0);
-      if (cur < 0 && cur != CHILD_EMPTY &&
-          prim_step<ANY, COUNT>(S, stack, n_tests, n_exact, min_t, min_lo, min_hi, ray_end, self_dmin, first_hit))
-        return true;
-    }
-    return cur == CHILD_EMPTY;
-#endif
   }
 };
 
@@ -744,6 +733,7 @@ __device__ __forceinline__ void trace_rays(const DevScene &S, const Policy &pol,
   cl.init(n, grab, gridDim.x * (TRAV_BLOCK / 64u), true);
   uint32_t next = 0, end = 0, idx = 0;
   bool exhausted = false, active = false;
+  bool unstored = false;  // the lane's finished walk has yet to write its result (see trace_two_lists)
   const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (TRAV_BLOCK / 64u) + (threadIdx.x >> 6)));
   if (!cl.first(wave, next, end)) { exhausted = true; next = end = 0; }
   w.cur = CHILD_EMPTY;
@@ -753,6 +743,10 @@ __device__ __forceinline__ void trace_rays(const DevScene &S, const Policy &pol,
     const int n_idle = __popcll(idle);
     if (n_idle >= REFILL && !exhausted) {
       if (next >= end && !cl.more(lane, next, end)) { exhausted = true; next = end = 0; }
+      if (unstored) {
+        pol.store(idx, w.result(), w.hit_prim >= 0);
+        unstored = false;
+      }
       if (next < end) {
         // idle lanes take the next rays in lane order
         const uint32_t mine = next + (uint32_t)__popcll(idle & below);
@@ -777,11 +771,12 @@ __device__ __forceinline__ void trace_rays(const DevScene &S, const Policy &pol,
       const bool done = w.template trip<ANY, COUNT>(S, stack, n_nodes, n_tests, n_exact, m0, min_t, min_lo, min_hi,
                                                     [&]() { return pol.ray_end(idx); }, [&]() { return pol.self_dmin(idx); });
       if (done) {
-        pol.store(idx, w.result(), w.hit_prim >= 0);
         active = false;
+        unstored = true;
       }
     }
   }
+  if (unstored) pol.store(idx, w.result(), w.hit_prim >= 0);
 }
 
 // Two ray lists in one launch of persistent waves: list E (closest-hit rays, policy
@@ -810,6 +805,7 @@ __device__ __forceinline__ void trace_two_lists(const DevScene &S, const PolE &p
   int phase = 0;  // list being claimed: 0 = E, 1 = S, 2 = both are handed out (wave-uniform)
   bool own_chunk = true;  // the wave has yet to take its own first chunk of the list of `phase`
   bool active = false, from_s = false;
+  bool unstored = false;  // the lane's finished walk has yet to write its result
   w.cur = CHILD_EMPTY;
   w.sp = 0;
   for (;;) {
@@ -827,6 +823,13 @@ __device__ __forceinline__ void trace_two_lists(const DevScene &S, const PolE &p
           next = end = 0;
           continue;
         }
+      }
+      // Results are written here, by all the lanes that have finished since the last refill at once,
+      // not by the few lanes that finish in any one trip.
+      if (unstored) {
+        if (from_s) ps.store(idx, w.result(), w.hit_prim >= 0);
+        else pe.store(idx, w.result(), w.hit_prim >= 0);
+        unstored = false;
       }
       const uint32_t mine = next + (uint32_t)__popcll(idle & below);
       if (!active && mine < end) {
@@ -853,11 +856,14 @@ __device__ __forceinline__ void trace_two_lists(const DevScene &S, const PolE &p
                                                   [&]() { return from_s ? ps.self_dmin(idx) : pe.self_dmin(idx); },
                                                   !CLOSEST_S && from_s);
       if (done) {
-        if (from_s) ps.store(idx, w.result(), w.hit_prim >= 0);
-        else pe.store(idx, w.result(), w.hit_prim >= 0);
         active = false;
+        unstored = true;
       }
     }
+  }
+  if (unstored) {
+    if (from_s) ps.store(idx, w.result(), w.hit_prim >= 0);
+    else pe.store(idx, w.result(), w.hit_prim >= 0);
   }
 }
 
@@ -1275,11 +1281,14 @@ __global__ void __launch_bounds__(256)
             VertexBuf vb, PathBuf pb, Compact cp, Ctl *ctl, int32_t depth, PixView pv, uint32_t p0, RoundPlan rp) {
   __shared__ uint32_t wsum[2][4];
   const uint32_t n = ctl->n_cur;
-  const uint32_t stride = gridDim.x * blockDim.x;
   const int nls = fp.nls;
   const int ns = rp.ns;
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  for (uint32_t base_i = blockIdx.x * blockDim.x; base_i < n; base_i += stride) {
+  {
+    // one workgroup per 256 entries (the grid covers the launch's upper bound; see ptamd_trace_list):
+    // without a loop around it the body keeps far fewer kernel arguments live in scalar registers
+    const uint32_t base_i = blockIdx.x * blockDim.x;
+    if (base_i >= n) return;
     const uint32_t i = base_i + threadIdx.x;
     const bool valid = i < n;
     bool do_nee = false, push = false;
@@ -1585,10 +1594,11 @@ __device__ __forceinline__ bool pending_visible(const DevScene &S, const VertexB
 __global__ void k_resolve(FrameParams fp, DevScene S, RayQ q, const int32_t *__restrict__ list, VertexBuf vb,
                           const SRay *__restrict__ rays, PathBuf pb, Ctl *ctl, int32_t depth) {
   const uint32_t n = ctl->n_cur;
-  const uint32_t stride = gridDim.x * blockDim.x;
   const int nls = fp.nls;
   unsigned long long verts = 0;
-  for (uint32_t base_i = blockIdx.x * blockDim.x; base_i < n; base_i += stride) {
+  {  // one workgroup per 256 entries, as k_shade
+    const uint32_t base_i = blockIdx.x * blockDim.x;
+    if (base_i >= n) return;
     const uint32_t i = base_i + threadIdx.x;
     if (i < n) {
       // Loads that do not depend on each other are issued together: the kernel does
@@ -1603,16 +1613,23 @@ __global__ void k_resolve(FrameParams fp, DevScene S, RayQ q, const int32_t *__r
         const size_t b = (size_t)i * nls;
         if ((nls & 3) == 0) {
           for (int q4 = 0; q4 < nls; q4 += 4) {
-            const uint32_t vw = *reinterpret_cast<const uint32_t *>(vb.vis + b + q4);
+            uint32_t vw = *reinterpret_cast<const uint32_t *>(vb.vis + b + q4);
+            // undecided slots first, one after the other (a rolled loop: the FP64 test's registers once)
+            if (vw & 0x02020202u) {
+#pragma unroll 1
+              for (int qq = 0; qq < 4; qq++) {
+                if (((vw >> (8 * qq)) & 0xffu) == 3u) {
+                  const uint32_t vs = pending_visible(S, vb, rays, i, b + q4 + qq) ? 1u : 0u;
+                  vw = (vw & ~(0xffu << (8 * qq))) | (vs << (8 * qq));
+                }
+              }
+            }
             Contrib cc[4];
 #pragma unroll
             for (int qq = 0; qq < 4; qq++) cc[qq] = vb.contrib[b + q4 + qq];  // whether visible or not
 #pragma unroll
-            for (int qq = 0; qq < 4; qq++) {
-              const uint32_t vs = (vw >> (8 * qq)) & 0xffu;
-              if (vs == 1u || (vs == 3u && pending_visible(S, vb, rays, i, b + q4 + qq)))
-                L = vadd(L, V(cc[qq].c[0], cc[qq].c[1], cc[qq].c[2]));
-            }
+            for (int qq = 0; qq < 4; qq++)
+              if (((vw >> (8 * qq)) & 0xffu) == 1u) L = vadd(L, V(cc[qq].c[0], cc[qq].c[1], cc[qq].c[2]));
           }
         } else {
           for (int qq = 0; qq < nls; qq++) {
@@ -2534,6 +2551,8 @@ int ptamd_trace_list(ptamd_context *c, const ptamd_pixel_list *list, int32_t sam
   const size_t elds = tl.lds_extend, slds = tl.lds_shadow;
   uint2 *gstack = tl.gstack;
   const int ggrid = grid_for(c, 8);
+  // k_shade runs one workgroup per 256 list entries; no list of this call is longer than a chunk's paths
+  const int shade_grid = (int)((px_per_chunk * n_samples + 255) / 256);
   PathBuf pb = c->pb;
   if (fp.accum) pb.pend[0] = pb.pend[1] = pb.pend[2] = nullptr;
   const PixView pv = view_of(list);
@@ -2565,10 +2584,10 @@ int ptamd_trace_list(ptamd_context *c, const ptamd_pixel_list *list, int32_t sam
       for (int k = 0; k < 3; k++) vb.hp[k] = c->q[cur ^ 1].o[k];  // one copy of the hit point serves both uses
       L.begin(PTAMD_K_SHADE);
       if (fp.hemisphere)
-        hipLaunchKernelGGL(k_shade<true>, ggrid, 256, 0, s, fp, c->S, c->q[cur], lst, c->hb, c->q[cur ^ 1], c->sq, vb, pb,
+        hipLaunchKernelGGL(k_shade<true>, shade_grid, 256, 0, s, fp, c->S, c->q[cur], lst, c->hb, c->q[cur ^ 1], c->sq, vb, pb,
                            c->cp, c->ctl, depth, pv, up0, rp);
       else
-        hipLaunchKernelGGL(k_shade<false>, ggrid, 256, 0, s, fp, c->S, c->q[cur], lst, c->hb, c->q[cur ^ 1], c->sq, vb, pb,
+        hipLaunchKernelGGL(k_shade<false>, shade_grid, 256, 0, s, fp, c->S, c->q[cur], lst, c->hb, c->q[cur ^ 1], c->sq, vb, pb,
                            c->cp, c->ctl, depth, pv, up0, rp);
       L.end();
       L.begin(PTAMD_K_OTHER);
@@ -2599,7 +2618,7 @@ int ptamd_trace_list(ptamd_context *c, const ptamd_pixel_list *list, int32_t sam
           L.end();
         }
         L.begin(PTAMD_K_RESOLVE);
-        hipLaunchKernelGGL(k_resolve, ggrid, 256, 0, s, fp, c->S, c->q[cur], lst, vb, (const SRay *)c->sq.ray, pb, c->ctl, depth);
+        hipLaunchKernelGGL(k_resolve, shade_grid, 256, 0, s, fp, c->S, c->q[cur], lst, vb, (const SRay *)c->sq.ray, pb, c->ctl, depth);
         hipLaunchKernelGGL(k_advance, 1, 1, 0, s, c->ctl);
         L.end();
       } else {

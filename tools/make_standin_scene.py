@@ -2,8 +2,10 @@
 """Writes the documented stand-ins for the headline scenes that are absent from the
 reference checkout (dae/sky/CBdragon.dae, dae/sky/CBlucy.dae).
 
-A stand-in is the CBempty Cornell box (walls, area light, camera: copied from
-scenes/CBempty.dae) plus one closed, manifold, procedurally generated diffuse
+A stand-in is the CBempty Cornell box (walls, light, camera: copied from
+scenes/CBempty.dae), its light declared an AREA light as in every other CB scene of the
+reference (CBbunny.dae, CBspheres.dae ...: CBempty.dae alone lacks the CGL <area> extra, which
+makes its light a point light that takes one sample whatever -l says), plus one closed, manifold, procedurally generated diffuse
 mesh of the requested size: the tube around a (2,3) torus knot with a smooth
 radial ripple. The mesh is deterministic (no random numbers), so every machine
 writes byte-identical files.
@@ -107,6 +109,22 @@ def write_scene(kind, out_path):
         </instance_geometry>
       </node>
 """
+    # the light: CGL area extra and radiance of dae/sky/CBbunny.dae (its size comes from the node's matrix)
+    point_light = """          <quadratic_attenuation>0.001599967</quadratic_attenuation>
+        </point>
+      </technique_common>
+"""
+    area_extra = """      <extra>
+        <technique profile="CGL">
+          <area>
+            <color sid="color">10 10 10</color>
+          </area>
+        </technique>
+      </extra>
+"""
+    if dae.count(point_light) != 1:
+        raise SystemExit("scenes/CBempty.dae: light element not found")
+    dae = dae.replace(point_light, point_light + area_extra, 1)
     dae = dae.replace("  </library_effects>", effect + "  </library_effects>", 1)
     dae = dae.replace("  </library_materials>", material + "  </library_materials>", 1)
     dae = dae.replace("  </library_geometries>", geometry + "  </library_geometries>", 1)
@@ -125,7 +143,11 @@ def standin_path(kind):
 
 def ensure(kind):
     path = standin_path(kind)
-    if not os.path.exists(path):
+    stale = True
+    if os.path.exists(path):
+        with open(path) as f:
+            stale = "<area>" not in f.read(4096)  # a file written before the light became an area light
+    if stale:
         write_scene(kind, path)
     return path
 

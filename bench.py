@@ -63,9 +63,11 @@ def parse_args():
     ap.add_argument("--cpu-cell", type=int, default=8, help="width in pixels of the CPU baseline's cell (full frame height)")
     ap.add_argument("--target-paths", type=int, default=16 << 20, help="see PixelSchedule.batches")
     ap.add_argument("--max-batches", type=int, default=32)
-    ap.add_argument("--per-pixel", type=int, default=0,
+    ap.add_argument("--per-pixel", type=int, default=-1,
                     help="1: pixels are traced ahead only as far as their statistics predict (see render_frame); "
-                         "0: all pixels of a round in lockstep")
+                         "0: all pixels of a round in lockstep; -1: the library's choice for the workload")
+    ap.add_argument("--exchange", default="frame", help="frame: pixels dealt once, one all-gather per frame; "
+                    "round: dealt again after every adaptive round, one all-gather per round")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL; the real thing) or gloo (rehearsal of the "
                     "multi-rank flow with several ranks on one GPU, rows staged through the host)")
     ap.add_argument("--pixel-stride", type=int, default=1,
@@ -246,12 +248,14 @@ def main():
     # reduction that counts a frame's samples before anything is timed
     int(torch.zeros(8, dtype=torch.int32, device=device).sum().item())
 
+    per_pixel = None if args.per_pixel < 0 else bool(args.per_pixel)
+
     def frame(seed):
         p = cabi.make_params(args.width, args.height, ns_aa=spp, max_ray_depth=args.depth,
                              ns_area_light=args.light_samples, seed=seed, specular=args.specular)
         hdr, cnt = distributed.render_frame(dev, p, rank=rank, world=world, device=device,
                                             pixel_stride=args.pixel_stride, target_paths=args.target_paths,
-                                            max_batches=args.max_batches, per_pixel=bool(args.per_pixel))
+                                            max_batches=args.max_batches, per_pixel=per_pixel, exchange=args.exchange)
         return cnt
 
     # Warm-up frames time every kernel class with HIP events and so find the dominant one; the timed
@@ -319,7 +323,9 @@ def main():
                 workload_name, args.width, args.height, spp, args.light_samples, args.depth,
                 ", specular mode" if args.specular else ""),
                 "samples_per_step": total_samples // max(args.steps, 1),
-                "parallelism": "pixels of each adaptive round dealt round-robin over %d GPU(s)" % world},
+                "parallelism": ("pixels dealt round-robin over %d GPU(s), " % world) +
+                               ("once per frame, one all-gather at its end" if args.exchange == "frame" else
+                                "again after every adaptive round, one all-gather per round")},
         }
         dev.set_event_classes(0xffffffff)
         cpu = None
@@ -336,7 +342,7 @@ def main():
                 pc = cabi.make_params(args.width, args.height, ns_aa=min(spp, 64), max_ray_depth=args.depth,
                                       ns_area_light=args.light_samples, seed=77, specular=args.specular)
                 distributed.render_frame(dev, pc, device=device, pixel_stride=args.pixel_stride,
-                                         per_pixel=bool(args.per_pixel))
+                                         per_pixel=per_pixel)
                 sc_ = dev.stats()
                 if sc_.rays:
                     own = {"nodes_per_ray": sc_.nodes_visited / 4.0 / sc_.rays, "prims_per_ray": sc_.prim_tests / sc_.rays}

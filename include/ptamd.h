@@ -289,7 +289,39 @@ int ptamd_unpack_rows(ptamd_context *ctx, const ptamd_pixel_list *list, int32_t 
 int ptamd_frame_resolve(ptamd_context *ctx, const double *d_state, double *d_hdr_out, int32_t *d_count_out,
                         void *stream);
 
+/* The whole adaptive loop of a frame (PathTracer::raytrace_pixel, pathtracer.cpp:234-272, for
+ * every listed pixel) in one call: ptamd_frame_begin, then rounds of ptamd_filter_list /
+ * ptamd_trace_list until every listed pixel has stopped, the per-pixel sums left in d_state
+ * ([w*h][6], zeroed by the caller; rows of pixels not listed stay untouched). d_pixels: n
+ * distinct pixel indices in device memory. The work is queued on `stream`; the call returns
+ * when the last round has been queued (it waits for earlier rounds' list lengths only).
+ * This is what one rank of a multi-GPU render runs on its share of the pixels, and what
+ * ptamd_render runs on the whole rectangle. */
+int ptamd_render_list(ptamd_context *ctx, const ptamd_render_params *params, const int32_t *d_pixels, int64_t n,
+                      double *d_state, void *stream);
+
 int ptamd_get_stats(ptamd_context *ctx, ptamd_stats *out);
+
+/* ---- several GPUs of one node (libptamd_multi.so: links RCCL) ---------------
+ * The counterpart of the reference's worker pool (numWorkerThreads threads taking tiles
+ * from a queue, raytraced_renderer.cpp:297-302, 326-328, 644-658), one host thread per
+ * GPU: the scene is replicated, pixel k of the frame's rectangle goes to GPU k % n, every
+ * GPU runs ptamd_render_list on its pixels, and the per-pixel sums are gathered on the first
+ * GPU with RCCL (one send per GPU) where the frame is resolved. Same frame for any n. */
+typedef struct ptamd_multi ptamd_multi;
+int ptamd_multi_create(const int32_t *device_ids, int32_t n, ptamd_multi **out);
+void ptamd_multi_destroy(ptamd_multi *m);
+int32_t ptamd_multi_size(const ptamd_multi *m);
+int ptamd_multi_upload_scene(ptamd_multi *m, const ptamd_scene_desc *desc);
+int ptamd_multi_set_camera(ptamd_multi *m, const ptamd_camera *cam);
+/* as ptamd_render */
+int ptamd_multi_render(ptamd_multi *m, const ptamd_render_params *params, double *hdr_out, int32_t *count_out);
+/* statistics of one GPU's share; seconds = wall time of the whole frame */
+int ptamd_multi_get_stats(ptamd_multi *m, int32_t rank, ptamd_stats *out);
+/* the deal's arithmetic: pixels of GPU `rank` out of n dealt to `world`, and the rows every
+ * GPU's block of the exchange holds (the largest share) */
+int64_t ptamd_multi_shard_size(int64_t n, int32_t rank, int32_t world);
+int64_t ptamd_multi_rows_per_rank(int64_t n, int32_t world);
 
 /* ---- output stage (host) --------------------------------------------------
  * HDRImageBuffer::toColor + ImageBuffer::update_pixel (src/util/image.h:183-198,

@@ -5,7 +5,7 @@ The package is a thin binding: the product is the C-ABI library built from
 HIP for gfx950). There is no CPU fallback: anything that renders raises
 ``PtamdError`` when the library or a GPU is missing.
 """
-from .api import Device, PtamdError, Scene, lib, make_params  # noqa: F401
+from .api import Device, MultiDevice, PtamdError, Scene, lib, lib_multi, make_params  # noqa: F401
 from . import cabi, ptar  # noqa: F401
 
-__all__ = ["Device", "PtamdError", "Scene", "lib", "make_params", "cabi", "ptar"]
+__all__ = ["Device", "MultiDevice", "lib_multi", "PtamdError", "Scene", "lib", "make_params", "cabi", "ptar"]

@@ -17,7 +17,7 @@ EXPORTS = (
     "ptamd_create", "ptamd_destroy", "ptamd_upload_scene", "ptamd_set_camera", "ptamd_set_max_paths",
     "ptamd_set_profiling", "ptamd_set_event_classes", "ptamd_render", "ptamd_trace_primary", "ptamd_frame_begin",
     "ptamd_trace_pixels", "ptamd_adaptive_filter", "ptamd_frame_resolve", "ptamd_get_stats",
-    "ptamd_trace_list", "ptamd_filter_list", "ptamd_filter_list_static", "ptamd_pack_rows", "ptamd_unpack_rows",
+    "ptamd_trace_list", "ptamd_filter_list", "ptamd_filter_list_static", "ptamd_render_list", "ptamd_pack_rows", "ptamd_unpack_rows",
     "ptamd_tonemap_rgba8", "ptamd_write_png", "ptamd_write_png_top_down", "ptamd_sampling_rate_rgba8",
 )
 
@@ -70,6 +70,7 @@ def lib():
     L.ptamd_trace_list.argtypes = [vp, pl, i32, i32, vp, vp]
     L.ptamd_filter_list.argtypes = [vp, pl, i32, vp, vp, vp, vp]
     L.ptamd_filter_list_static.argtypes = [vp, pl, i32, vp, vp, vp, vp]
+    L.ptamd_render_list.argtypes = [vp, C.POINTER(RenderParams), vp, i64, vp, vp]
     L.ptamd_pack_rows.argtypes = [vp, pl, vp, vp, vp]
     L.ptamd_unpack_rows.argtypes = [vp, pl, i32, i32, vp, i64, vp, vp]
     L.ptamd_get_stats.argtypes = [vp, C.POINTER(Stats)]
@@ -79,6 +80,47 @@ def lib():
     L.ptamd_sampling_rate_rgba8.argtypes = [pi, i32, i32, i32, C.POINTER(C.c_uint32)]
     _LIB = L
     return L
+
+
+EXPORTS_MULTI = (
+    "ptamd_multi_create", "ptamd_multi_destroy", "ptamd_multi_size", "ptamd_multi_upload_scene",
+    "ptamd_multi_set_camera", "ptamd_multi_render", "ptamd_multi_get_stats", "ptamd_multi_shard_size",
+    "ptamd_multi_rows_per_rank",
+)
+_LIB_MULTI = None
+
+
+def lib_multi():
+    """libptamd_multi.so: several GPUs of one node from C++ (host threads + RCCL). Loaded on demand."""
+    global _LIB_MULTI
+    if _LIB_MULTI is not None:
+        return _LIB_MULTI
+    try:
+        # torch ships its own copies of the ROCm libraries (RCCL among them); if it is going to live in
+        # this process they must be the ones loaded first, or the two copies' exit handlers collide
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    lib()  # libptamd.so first (libptamd_multi.so links it)
+    path = os.path.join(os.path.dirname(lib_path()), "libptamd_multi.so")
+    if not os.path.exists(path):
+        raise PtamdError("%s is missing: build it with `make -C pathtracer_amd/csrc`" % path)
+    M = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
+    M.ptamd_multi_create.argtypes = [C.POINTER(i32), i32, C.POINTER(vp)]
+    M.ptamd_multi_destroy.argtypes = [vp]
+    M.ptamd_multi_destroy.restype = None
+    M.ptamd_multi_size.argtypes = [vp]
+    M.ptamd_multi_upload_scene.argtypes = [vp, C.POINTER(SceneDesc)]
+    M.ptamd_multi_set_camera.argtypes = [vp, C.POINTER(Camera)]
+    M.ptamd_multi_render.argtypes = [vp, C.POINTER(RenderParams), C.POINTER(C.c_double), C.POINTER(C.c_int32)]
+    M.ptamd_multi_get_stats.argtypes = [vp, i32, C.POINTER(Stats)]
+    M.ptamd_multi_shard_size.argtypes = [i64, i32, i32]
+    M.ptamd_multi_shard_size.restype = i64
+    M.ptamd_multi_rows_per_rank.argtypes = [i64, i32]
+    M.ptamd_multi_rows_per_rank.restype = i64
+    _LIB_MULTI = M
+    return M
 
 
 def _check(rc):
@@ -114,6 +156,47 @@ class Scene:
     def close(self):
         if self._h:
             lib().ptamd_scene_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class MultiDevice:
+    """Several GPUs of this node rendering a frame together (ptamd_multi_*, C++ threads + RCCL)."""
+
+    def __init__(self, device_ids):
+        ids = (C.c_int32 * len(device_ids))(*device_ids)
+        self._h = C.c_void_p()
+        _check(lib_multi().ptamd_multi_create(ids, len(device_ids), C.byref(self._h)))
+        self._keep = None
+
+    def upload(self, scene):
+        desc = scene.desc if hasattr(scene, "desc") else scene
+        self._keep = scene
+        _check(lib_multi().ptamd_multi_upload_scene(self._h, C.byref(desc)))
+
+    def set_camera(self, cam):
+        _check(lib_multi().ptamd_multi_set_camera(self._h, C.byref(cam)))
+
+    def render(self, params):
+        hdr = np.zeros((params.h, params.w, 3), np.float64)
+        cnt = np.zeros((params.h, params.w), np.int32)
+        _check(lib_multi().ptamd_multi_render(self._h, C.byref(params), hdr.ctypes.data_as(C.POINTER(C.c_double)),
+                                              cnt.ctypes.data_as(C.POINTER(C.c_int32))))
+        return hdr, cnt
+
+    def stats(self, rank=0):
+        st = Stats()
+        _check(lib_multi().ptamd_multi_get_stats(self._h, rank, C.byref(st)))
+        return st
+
+    def close(self):
+        if self._h:
+            lib_multi().ptamd_multi_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):
@@ -224,6 +307,16 @@ def tonemap(hdr):
     out = np.zeros(h * w, np.uint32)
     _check(lib().ptamd_tonemap_rgba8(a.ctypes.data_as(C.POINTER(C.c_double)), w, h,
                                      out.ctypes.data_as(C.POINTER(C.c_uint32))))
+    return out.reshape(h, w)
+
+
+def sampling_rate(count, ns_aa):
+    """save_sampling_rate_image's colouring of a sample-count map (top row first), as uint32 RGBA."""
+    h, w = count.shape
+    c = np.ascontiguousarray(count, np.int32)
+    out = np.zeros(h * w, np.uint32)
+    _check(lib().ptamd_sampling_rate_rgba8(c.ctypes.data_as(C.POINTER(C.c_int32)), w, h, ns_aa,
+                                           out.ctypes.data_as(C.POINTER(C.c_uint32))))
     return out.reshape(h, w)
 
 

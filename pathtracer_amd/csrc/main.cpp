@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <iostream>
 #include <string>
+#include <vector>
 
 #include "../../include/ptamd.h"
 #include "renderer.h"
@@ -30,7 +31,7 @@ static void usage(const char *binaryName) {
   printf("  -c  <FILENAME>   Load camera settings file\n");
   printf("  -a  <INT> <FLOAT> Samples per batch and tolerance for adaptive sampling\n");
   printf("  -H               Enable hemisphere sampling for direct lighting\n");
-  printf("  -g  <INT>        GPU to render on (default 0)\n");
+  printf("  -g  <INT>[,<INT>...]  GPU(s) to render on (default 0; several: pixels dealt round-robin, RCCL gather)\n");
   printf("  -S  <INT>        Seed of the per-pixel random-number generator (default 0)\n");
   printf("  -C               Count BVH node visits and primitive tests (slower)\n");
   printf("  -X               Ideal mirror / refraction / glass BSDFs instead of the reference's black stubs\n");
@@ -45,6 +46,7 @@ int main(int argc, char **argv) {
   double lensRadius = 0.0, focalDistance = 4.7;
   size_t w = 0, h = 0, x = (size_t)-1, y = 0, dx = 0, dy = 0;
   int device = 0;
+  std::vector<int> devices;
   unsigned long long seed = 0;
   std::string output_file_name, cam_settings, sceneFilePath;
   int opt;
@@ -85,7 +87,17 @@ int main(int argc, char **argv) {
         hemisphere = true;
         optind--;
         break;
-      case 'g': device = atoi(optarg); break;
+      case 'g': {  // one GPU, or several: -g 0,1,2,3
+        devices.clear();
+        for (const char *q = optarg; *q;) {
+          devices.push_back(atoi(q));
+          while (*q && *q != ',') q++;
+          if (*q == ',') q++;
+        }
+        if (devices.empty()) { usage(argv[0]); return 1; }
+        device = devices[0];
+        break;
+      }
       case 'S': seed = strtoull(optarg, nullptr, 10); break;
       case 'C': counters = true; break;
       case 'X': specular = true; break;
@@ -111,6 +123,7 @@ int main(int argc, char **argv) {
   }
   RaytracedRenderer renderer(ns_aa, max_ray_depth, accumulate, ns_area_light, 1, 1, 1, num_threads, samples_per_batch,
                              max_tolerance, nullptr, hemisphere, sceneFile, lensRadius, focalDistance, device);
+  if (devices.size() > 1 && !renderer.set_devices(devices)) return 2;
   renderer.pt->seed = seed;
   renderer.pt->specular = specular;
   renderer.profile_counters = counters;

@@ -190,6 +190,7 @@ struct RoundPlan {
   double tol;
   int32_t sample_base, ns, batch, ns_aa;
   int32_t predict;  // 0: every pixel gets all ns samples (a launch too small for dropped samples to matter)
+  double margin;    // samples planned per sample predicted (see planned)
   __device__ __forceinline__ int32_t first_of(const double *st) const {
     return sample_base >= 0 ? sample_base : (int32_t)st[5];
   }
@@ -203,8 +204,8 @@ struct RoundPlan {
       const double s1 = st[0], s2 = st[1];
       const double mean = s1 / n, var = (s2 - s1 * s1 / n) / (n - 1);
       const double c = 1.96 / tol;
-      // 1.5: erring on the long side costs a few dropped samples, erring on the short side a round
-      const double need = 1.5 * (c * c * var / (mean * mean) - n);
+      // margin (1.5): erring on the long side costs a few dropped samples, erring on the short side a round
+      const double need = margin * (c * c * var / (mean * mean) - n);
       if (need == need) {  // not NaN
         double kb = ceil(need / batch);
         kb = kb < 1 ? 1 : (kb > (double)(ns / batch) ? (double)(ns / batch) : kb);
@@ -1853,6 +1854,17 @@ static __device__ __align__(256) uint32_t scratch[FILTER_STATIC_BLOCKS];
     }                                                                                      \
   } while (0)
 
+// Frame-level buffers of ptamd_render / ptamd_render_list (see ensure_frame_scratch)
+struct FrameScratch {
+  int32_t *d_list[3] = {nullptr, nullptr, nullptr};  // two survivor lists in turn; [2]: ptamd_render's first list
+  int64_t cap_list = 0;
+  double *d_state = nullptr, *d_hdr = nullptr;
+  int32_t *d_count = nullptr;
+  int64_t cap_pix = 0;
+  int64_t *d_n = nullptr, *h_n = nullptr;  // two list lengths on the device, their pinned host copies
+  hipEvent_t ev[2] = {nullptr, nullptr};
+};
+
 struct ptamd_context {
   int device = 0;
   int num_cu = 256;
@@ -1869,6 +1881,7 @@ struct ptamd_context {
   FrameParams fp{};
   // work buffers
   bool clear_ctl = false;  // the next ptamd_trace_list zeroes the device-side counters first
+  double plan_margin = 1.5;  // RoundPlan::margin (PTAMD_PLAN_MARGIN in the environment: experiments)
   bool trace_two = true;  // bounce rays of depth d + 1 and shadow rays of depth d in one launch (PTAMD_TRACE_TWO=0: apart)
   int64_t max_paths = 16 << 20;  // paths per launch: large launches amortise the drain of the slowest waves
   int64_t cap_paths = 0;
@@ -1885,6 +1898,7 @@ struct ptamd_context {
   Ctl *ctl = nullptr;
   uint32_t *block_count = nullptr;
   size_t block_count_cap = 0;
+  FrameScratch fs;
   double scene_max_coord = 0;
   uint32_t *static_block_count = nullptr;  // this GPU's copy of `scratch` (ptamd_filter_list_static)
   uint2 *gstack = nullptr;  // overflow levels of the per-lane traversal stacks
@@ -1906,6 +1920,7 @@ struct ptamd_context {
 
 namespace {
 
+void free_frame_scratch(ptamd_context *c);
 void free_scene(ptamd_context *c) {
   for (void *p : c->scene_allocs) (void)hipFree(p);
   c->scene_allocs.clear();
@@ -2084,6 +2099,7 @@ int ptamd_create(int32_t device_id, ptamd_context **out) {
   if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) c->num_cu = prop.multiProcessorCount;
   if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) c->own_stream = nullptr;
   if (const char *e = getenv("PTAMD_TRACE_TWO")) c->trace_two = atoi(e) != 0;
+  if (const char *e = getenv("PTAMD_PLAN_MARGIN")) { const double m = atof(e); if (m >= 1.0 && m <= 8.0) c->plan_margin = m; }
   // The counters live apart from the work buffers: those are reallocated when a later round needs
   // more room, and a frame's statistics must survive that.
   if (hipMalloc((void **)&c->ctl, sizeof(Ctl)) != hipSuccess || hipMemset(c->ctl, 0, sizeof(Ctl)) != hipSuccess) {
@@ -2114,6 +2130,7 @@ void ptamd_destroy(ptamd_context *c) {
   collect_events(c);
   for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
   free_scene(c);
+  free_frame_scratch(c);
   if (c->slab) (void)hipFree(c->slab);
   if (c->ctl) (void)hipFree(c->ctl);
   if (c->block_count) (void)hipFree(c->block_count);
@@ -2558,7 +2575,7 @@ int ptamd_trace_list(ptamd_context *c, const ptamd_pixel_list *list, int32_t sam
   const PixView pv = view_of(list);
   // per-pixel prediction only where a launch is big enough for dropped samples to cost time
   const RoundPlan rp{d_state, c->params.max_tolerance, sample_base, n_samples, c->params.samples_per_batch, c->params.ns_aa,
-                     n * n_samples >= (1 << 20) ? 1 : 0};
+                     n * n_samples >= (1 << 20) ? 1 : 0, c->plan_margin};
   Launcher L{c, s};
   const int depths = std::max(1, fp.max_ray_depth);
   for (int64_t p0 = 0; p0 < n; p0 += px_per_chunk) {
@@ -2789,70 +2806,86 @@ int ptamd_get_stats(ptamd_context *c, ptamd_stats *out) {
   return PTAMD_OK;
 }
 
-int ptamd_render(ptamd_context *c, const ptamd_render_params *p, double *hdr_out, int32_t *count_out) {
-  if (!c || !p || !hdr_out || !count_out) { ptamd::set_error("null argument"); return PTAMD_ERR_ARG; }
+namespace {
+// Buffers of ptamd_render / ptamd_render_list, kept by the context between frames (grown on demand).
+int ensure_frame_scratch(ptamd_context *c, int64_t npix, int64_t nlist, bool outputs) {
+  FrameScratch &f = c->fs;
+  if (!f.d_n) {
+    HIPCHK(hipMalloc((void **)&f.d_n, 2 * sizeof(int64_t)));
+    HIPCHK(hipHostMalloc((void **)&f.h_n, 2 * sizeof(int64_t), hipHostMallocDefault));
+    HIPCHK(hipEventCreateWithFlags(&f.ev[0], hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&f.ev[1], hipEventDisableTiming));
+  }
+  if (nlist > f.cap_list) {
+    HIPCHK(hipDeviceSynchronize());
+    for (int k = 0; k < 3; k++) { if (f.d_list[k]) HIPCHK(hipFree(f.d_list[k])); f.d_list[k] = nullptr; }
+    for (int k = 0; k < 3; k++) HIPCHK(hipMalloc((void **)&f.d_list[k], std::max<int64_t>(nlist, 1) * sizeof(int32_t)));
+    f.cap_list = nlist;
+  }
+  if (outputs && npix > f.cap_pix) {
+    HIPCHK(hipDeviceSynchronize());
+    if (f.d_state) HIPCHK(hipFree(f.d_state));
+    if (f.d_hdr) HIPCHK(hipFree(f.d_hdr));
+    if (f.d_count) HIPCHK(hipFree(f.d_count));
+    f.d_state = f.d_hdr = nullptr; f.d_count = nullptr;
+    HIPCHK(hipMalloc((void **)&f.d_state, npix * 6 * sizeof(double)));
+    HIPCHK(hipMalloc((void **)&f.d_hdr, npix * 3 * sizeof(double)));
+    HIPCHK(hipMalloc((void **)&f.d_count, npix * sizeof(int32_t)));
+    f.cap_pix = npix;
+  }
+  return PTAMD_OK;
+}
+void free_frame_scratch(ptamd_context *c) {
+  FrameScratch &f = c->fs;
+  for (int k = 0; k < 3; k++) if (f.d_list[k]) (void)hipFree(f.d_list[k]);
+  if (f.d_state) (void)hipFree(f.d_state);
+  if (f.d_hdr) (void)hipFree(f.d_hdr);
+  if (f.d_count) (void)hipFree(f.d_count);
+  if (f.d_n) (void)hipFree(f.d_n);
+  if (f.h_n) (void)hipHostFree(f.h_n);
+  for (hipEvent_t e : f.ev) if (e) (void)hipEventDestroy(e);
+  f = FrameScratch{};
+}
+}  // namespace
+
+int ptamd_render_list(ptamd_context *c, const ptamd_render_params *p, const int32_t *d_pixels, int64_t n, double *d_state,
+                      void *stream) {
+  if (!c || !p || n < 0 || (n > 0 && (!d_pixels || !d_state))) { ptamd::set_error("invalid arguments to ptamd_render_list"); return PTAMD_ERR_ARG; }
   int rc = ptamd_frame_begin(c, p);
   if (rc) return rc;
-  const int x0 = std::max(0, p->x0), y0 = std::max(0, p->y0), x1 = std::min(p->w, p->x1), y1 = std::min(p->h, p->y1);
-  const int64_t npix = (int64_t)p->w * p->h;
-  const int64_t nrect = (x1 > x0 && y1 > y0) ? (int64_t)(x1 - x0) * (y1 - y0) : 0;
-  double *d_state = nullptr, *d_hdr = nullptr;
-  int32_t *d_list[2] = {nullptr, nullptr}, *d_count = nullptr;
-  int64_t *d_n = nullptr, *h_n = nullptr;  // two list lengths on the device, their pinned host copies
-  hipEvent_t ev[2] = {nullptr, nullptr};
-  auto cleanup = [&]() {
-    (void)hipFree(d_state); (void)hipFree(d_hdr); (void)hipFree(d_list[0]); (void)hipFree(d_list[1]);
-    (void)hipFree(d_count); (void)hipFree(d_n);
-    if (h_n) (void)hipHostFree(h_n);
-    for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
-  };
-#define HIPCHK_CLEAN(expr)                                                              \
-  do {                                                                                  \
-    hipError_t e_ = (expr);                                                             \
-    if (e_ != hipSuccess) {                                                             \
-      ptamd::set_error(std::string(#expr) + ": " + hipGetErrorString(e_));              \
-      cleanup();                                                                        \
-      return PTAMD_ERR_DEVICE;                                                          \
-    }                                                                                   \
-  } while (0)
-  HIPCHK_CLEAN(hipMalloc((void **)&d_state, npix * 6 * sizeof(double)));
-  HIPCHK_CLEAN(hipMalloc((void **)&d_hdr, npix * 3 * sizeof(double)));
-  HIPCHK_CLEAN(hipMalloc((void **)&d_count, npix * sizeof(int32_t)));
-  HIPCHK_CLEAN(hipMalloc((void **)&d_list[0], std::max<int64_t>(nrect, 1) * sizeof(int32_t)));
-  HIPCHK_CLEAN(hipMalloc((void **)&d_list[1], std::max<int64_t>(nrect, 1) * sizeof(int32_t)));
-  HIPCHK_CLEAN(hipMalloc((void **)&d_n, 2 * sizeof(int64_t)));
-  HIPCHK_CLEAN(hipHostMalloc((void **)&h_n, 2 * sizeof(int64_t), hipHostMallocDefault));
-  HIPCHK_CLEAN(hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
-  HIPCHK_CLEAN(hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
-  hipStream_t s = c->own_stream;
-  HIPCHK_CLEAN(hipMemsetAsync(d_state, 0, npix * 6 * sizeof(double), s));
-  if (nrect) hipLaunchKernelGGL(k_iota, grid_for(c, 4), 256, 0, s, d_list[0], (uint32_t)nrect, p->w, x0, y0, x1 - x0);
+  if (n == 0) return PTAMD_OK;
+  rc = ensure_frame_scratch(c, 0, n, false);
+  if (rc) return rc;
+  FrameScratch &f = c->fs;
+  hipStream_t s = (hipStream_t)stream;
   {
-    const int64_t init[2] = {nrect, nrect};
-    HIPCHK_CLEAN(hipMemcpyAsync(d_n, init, sizeof init, hipMemcpyHostToDevice, s));
+    const int64_t init[2] = {n, n};
+    HIPCHK(hipMemcpyAsync(f.d_n, init, sizeof init, hipMemcpyHostToDevice, s));
   }
-  HIPCHK_CLEAN(hipStreamSynchronize(s));
-  auto t0 = std::chrono::steady_clock::now();
   // Round r traces the survivors of the adaptive test after round r - 1. Their
   // number stays on the device; the host only needs an upper bound to size the
   // launches, and uses the count of one round earlier, read back asynchronously,
   // so the GPU never waits for the host between rounds.
-  int64_t n_known = nrect;
+  const int32_t *lists[2] = {d_pixels, nullptr};  // current list: the caller's, then the context's two in turn
+  int32_t *own[2] = {f.d_list[0], f.d_list[1]};
+  int64_t n_known = n;
   int cur = 0, done = 0;
   for (int r = 0; done < p->ns_aa && n_known > 0; r++) {
-    ptamd_pixel_list l{d_list[cur], d_n + cur, 0, n_known, 0, 1};
+    ptamd_pixel_list l{lists[cur], f.d_n + cur, 0, n_known, 0, 1};
     if (r > 0) {
-      rc = ptamd_filter_list(c, &l, done, d_state, d_list[cur ^ 1], d_n + (cur ^ 1), s);
-      if (rc) { cleanup(); return rc; }
+      int32_t *out = own[r & 1];
+      rc = ptamd_filter_list(c, &l, done, d_state, out, f.d_n + (cur ^ 1), s);
+      if (rc) return rc;
       cur ^= 1;
-      HIPCHK_CLEAN(hipMemcpyAsync(h_n + (r & 1), d_n + cur, sizeof(int64_t), hipMemcpyDeviceToHost, s));
-      HIPCHK_CLEAN(hipEventRecord(ev[r & 1], s));
+      lists[cur] = out;
+      HIPCHK(hipMemcpyAsync(f.h_n + (r & 1), f.d_n + cur, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+      HIPCHK(hipEventRecord(f.ev[r & 1], s));
       if (r > 1) {
-        HIPCHK_CLEAN(hipEventSynchronize(ev[(r - 1) & 1]));
-        n_known = h_n[(r - 1) & 1];
+        HIPCHK(hipEventSynchronize(f.ev[(r - 1) & 1]));
+        n_known = f.h_n[(r - 1) & 1];
         if (n_known == 0) break;
       }
-      l = ptamd_pixel_list{d_list[cur], d_n + cur, 0, n_known, 0, 1};
+      l = ptamd_pixel_list{lists[cur], f.d_n + cur, 0, n_known, 0, 1};
     }
     // a round too small to fill the GPU traces several batches per pixel ahead of
     // their adaptive tests (k_accumulate applies them and drops what was not needed)
@@ -2862,17 +2895,35 @@ int ptamd_render(ptamd_context *c, const ptamd_render_params *p, double *hdr_out
     int64_t k = std::max<int64_t>(1, std::min<int64_t>(target / std::max<int64_t>(paths, 1), 32));
     const int ns = (int)std::min<int64_t>(k * p->samples_per_batch, p->ns_aa - done);
     rc = ptamd_trace_list(c, &l, done, ns, d_state, s);
-    if (rc) { cleanup(); return rc; }
+    if (rc) return rc;
     done += ns;
   }
-  rc = ptamd_frame_resolve(c, d_state, d_hdr, d_count, s);
-  if (rc) { cleanup(); return rc; }
-  HIPCHK_CLEAN(hipStreamSynchronize(s));
+  return PTAMD_OK;
+}
+
+int ptamd_render(ptamd_context *c, const ptamd_render_params *p, double *hdr_out, int32_t *count_out) {
+  if (!c || !p || !hdr_out || !count_out) { ptamd::set_error("null argument"); return PTAMD_ERR_ARG; }
+  HIPCHK(hipSetDevice(c->device));
+  const int x0 = std::max(0, p->x0), y0 = std::max(0, p->y0), x1 = std::min(p->w, p->x1), y1 = std::min(p->h, p->y1);
+  const int64_t npix = (int64_t)p->w * p->h;
+  const int64_t nrect = (x1 > x0 && y1 > y0) ? (int64_t)(x1 - x0) * (y1 - y0) : 0;
+  if (npix <= 0) { ptamd::set_error("empty frame"); return PTAMD_ERR_ARG; }
+  int rc = ensure_frame_scratch(c, npix, nrect, true);
+  if (rc) return rc;
+  FrameScratch &f = c->fs;
+  hipStream_t s = c->own_stream;
+  HIPCHK(hipMemsetAsync(f.d_state, 0, npix * 6 * sizeof(double), s));
+  if (nrect) hipLaunchKernelGGL(k_iota, grid_for(c, 4), 256, 0, s, f.d_list[2], (uint32_t)nrect, p->w, x0, y0, x1 - x0);
+  HIPCHK(hipStreamSynchronize(s));
+  auto t0 = std::chrono::steady_clock::now();
+  rc = ptamd_render_list(c, p, f.d_list[2], nrect, f.d_state, s);
+  if (rc) return rc;
+  rc = ptamd_frame_resolve(c, f.d_state, f.d_hdr, f.d_count, s);
+  if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(s));
   c->stats.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-  HIPCHK_CLEAN(hipMemcpy(hdr_out, d_hdr, npix * 3 * sizeof(double), hipMemcpyDeviceToHost));
-  HIPCHK_CLEAN(hipMemcpy(count_out, d_count, npix * sizeof(int32_t), hipMemcpyDeviceToHost));
-  cleanup();
-#undef HIPCHK_CLEAN
+  HIPCHK(hipMemcpy(hdr_out, f.d_hdr, npix * 3 * sizeof(double), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(count_out, f.d_count, npix * sizeof(int32_t), hipMemcpyDeviceToHost));
   return PTAMD_OK;
 }
 

@@ -1,5 +1,7 @@
 #include "renderer.h"
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cstdio>
 #include <ctime>
@@ -54,13 +56,54 @@ ptamd_render_params PathTracer::make_params(size_t x0, size_t y0, size_t x1, siz
   return p;
 }
 
+// libptamd_multi.so is loaded only when several GPUs are asked for: it links RCCL, which a
+// single-GPU run has no use for.
+struct MultiGpu {
+  void *lib = nullptr;
+  ptamd_multi *h = nullptr;
+  int (*create)(const int32_t *, int32_t, ptamd_multi **) = nullptr;
+  void (*destroy)(ptamd_multi *) = nullptr;
+  int (*upload_scene)(ptamd_multi *, const ptamd_scene_desc *) = nullptr;
+  int (*set_camera)(ptamd_multi *, const ptamd_camera *) = nullptr;
+  int (*render)(ptamd_multi *, const ptamd_render_params *, double *, int32_t *) = nullptr;
+  int (*get_stats)(ptamd_multi *, int32_t, ptamd_stats *) = nullptr;
+  std::vector<int32_t> devices;
+  ~MultiGpu() {
+    if (h && destroy) destroy(h);
+    if (lib) dlclose(lib);
+  }
+  bool load(std::string &error) {
+    Dl_info info;
+    std::string dir = ".";
+    if (dladdr((void *)&ptamd_create, &info) && info.dli_fname) {
+      dir = info.dli_fname;
+      const size_t slash = dir.find_last_of('/');
+      dir = slash == std::string::npos ? "." : dir.substr(0, slash);
+    }
+    const std::string path = dir + "/libptamd_multi.so";
+    lib = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
+    if (!lib) { error = std::string("cannot load ") + path + ": " + dlerror(); return false; }
+    create = (decltype(create))dlsym(lib, "ptamd_multi_create");
+    destroy = (decltype(destroy))dlsym(lib, "ptamd_multi_destroy");
+    upload_scene = (decltype(upload_scene))dlsym(lib, "ptamd_multi_upload_scene");
+    set_camera = (decltype(set_camera))dlsym(lib, "ptamd_multi_set_camera");
+    render = (decltype(render))dlsym(lib, "ptamd_multi_render");
+    get_stats = (decltype(get_stats))dlsym(lib, "ptamd_multi_get_stats");
+    if (!create || !destroy || !upload_scene || !set_camera || !render || !get_stats) {
+      error = path + " lacks an entry point";
+      return false;
+    }
+    return true;
+  }
+};
+
 int PathTracer::raytrace_rect(size_t x0, size_t y0, size_t x1, size_t y1) {
-  if (!bvh) return PTAMD_ERR_STATE;
+  if (!bvh && !multi) return PTAMD_ERR_STATE;
   const size_t w = sampleBuffer.w, h = sampleBuffer.h;
   ptamd_render_params p = make_params(x0, y0, x1, y1);
   std::vector<double> hdr(w * h * 3);
   std::vector<int32_t> cnt(w * h);
-  int rc = ptamd_render(bvh, &p, hdr.data(), cnt.data());
+  int rc = multi ? multi->render(multi->h, &p, hdr.data(), cnt.data()) : ptamd_render(bvh, &p, hdr.data(), cnt.data());
   if (rc) return rc;
   for (size_t y = y0; y < y1 && y < h; y++)
     for (size_t x = x0; x < x1 && x < w; x++) {
@@ -104,7 +147,22 @@ RaytracedRenderer::RaytracedRenderer(size_t ns_aa, size_t max_ray_depth, bool is
   device = device_;
 }
 
+bool RaytracedRenderer::set_devices(const std::vector<int> &device_ids) {
+  if (state != INIT || bvh || multi || device_ids.empty()) return false;
+  if (device_ids.size() == 1) { device = device_ids[0]; return true; }
+  MultiGpu *m = new MultiGpu;
+  if (!m->load(error)) {
+    fprintf(stderr, "[PathTracer] %s\n", error.c_str());
+    delete m;
+    return false;
+  }
+  m->devices.assign(device_ids.begin(), device_ids.end());
+  multi = m;
+  return true;
+}
+
 RaytracedRenderer::~RaytracedRenderer() {
+  delete multi;
   if (bvh) ptamd_destroy(bvh);
   if (scene) ptamd_scene_free(scene);
   delete pt;
@@ -121,10 +179,16 @@ void RaytracedRenderer::set_scene(ptamd_scene *new_scene) {  // raytraced_render
   // build_accel (raytraced_renderer.cpp:351-375): the tree was built with the
   // scene; here it is flattened and copied to the device
   fprintf(stdout, "[PathTracer] Building BVH... Done! (%.4f sec)\n", ptamd_scene_build_seconds(scene));
-  int rc = ptamd_create(device, &bvh);
   ptamd_scene_desc desc;
-  if (!rc) rc = ptamd_scene_get_desc(scene, &desc);
-  if (!rc) rc = ptamd_upload_scene(bvh, &desc);
+  int rc = ptamd_scene_get_desc(scene, &desc);
+  if (multi) {
+    if (multi->h) { multi->destroy(multi->h); multi->h = nullptr; }
+    if (!rc) rc = multi->create(multi->devices.data(), (int32_t)multi->devices.size(), &multi->h);
+    if (!rc) rc = multi->upload_scene(multi->h, &desc);
+  } else {
+    if (!rc) rc = ptamd_create(device, &bvh);
+    if (!rc) rc = ptamd_upload_scene(bvh, &desc);
+  }
   if (rc) {
     error = ptamd_last_error();
     fprintf(stderr, "[PathTracer] %s\n", error.c_str());
@@ -132,7 +196,8 @@ void RaytracedRenderer::set_scene(ptamd_scene *new_scene) {  // raytraced_render
     bvh = nullptr;
     return;
   }
-  fprintf(stdout, "[PathTracer] Uploaded %d primitives, %d BVH nodes to GPU %d\n", desc.n_prims, desc.n_nodes, device);
+  if (multi) fprintf(stdout, "[PathTracer] Uploaded %d primitives, %d BVH nodes to %d GPUs\n", desc.n_prims, desc.n_nodes, (int)multi->devices.size());
+  else fprintf(stdout, "[PathTracer] Uploaded %d primitives, %d BVH nodes to GPU %d\n", desc.n_prims, desc.n_nodes, device);
   if (has_valid_configuration()) state = READY;
 }
 
@@ -178,16 +243,17 @@ void RaytracedRenderer::clear() {  // raytraced_renderer.cpp:241-254
 
 void RaytracedRenderer::start_raytracing() {  // raytraced_renderer.cpp:268-329
   if (state != READY) return;
-  if (!bvh) { error = "no device context"; return; }
+  if (!bvh && !(multi && multi->h)) { error = "no device context"; return; }
   state = RENDERING;
   const size_t width = frameBuffer.w, height = frameBuffer.h;
   pt->clear();
   pt->set_frame_size(width, height);
   pt->bvh = bvh;
+  pt->multi = multi;
   pt->camera = camera;
   pt->scene = scene;
-  int rc = ptamd_set_camera(bvh, camera);
-  if (!rc) rc = ptamd_set_profiling(bvh, 0, profile_counters ? 1 : 0);
+  int rc = multi ? multi->set_camera(multi->h, camera) : ptamd_set_camera(bvh, camera);
+  if (!rc && !multi) rc = ptamd_set_profiling(bvh, 0, profile_counters ? 1 : 0);
   size_t x0 = 0, y0 = 0, x1 = width, y1 = height;
   if (!render_cell) {
     frameBuffer.clear();
@@ -206,7 +272,19 @@ void RaytracedRenderer::start_raytracing() {  // raytraced_renderer.cpp:268-329
     return;
   }
   pt->write_to_framebuffer(frameBuffer, x0, y0, x1, y1);
-  ptamd_get_stats(bvh, &stats);
+  if (multi) {
+    // the frame's wall time and the sums of the GPUs' counters
+    ptamd_stats part{};
+    stats = ptamd_stats{};
+    for (size_t r = 0; r < multi->devices.size(); r++) {
+      multi->get_stats(multi->h, (int32_t)r, &part);
+      stats.seconds = part.seconds;
+      stats.samples += part.samples; stats.rays += part.rays; stats.shadow_rays += part.shadow_rays;
+      stats.path_vertices += part.path_vertices; stats.prim_tests += part.prim_tests; stats.nodes_visited += part.nodes_visited;
+    }
+  } else {
+    ptamd_get_stats(bvh, &stats);
+  }
   // raytraced_renderer.cpp:668-672
   fprintf(stdout, "100%%! (%.4fs)\n", stats.seconds);
   fprintf(stdout, "[PathTracer] BVH traced %llu rays.\n", (unsigned long long)stats.rays);

@@ -13,6 +13,7 @@
 #include "../../include/ptamd.h"
 
 namespace ptamd {
+struct MultiGpu;  // libptamd_multi.so's entry points and one ptamd_multi handle (renderer.cpp)
 
 // src/util/image.h:20-100 (RGBA8, R in the low byte, row 0 = bottom)
 struct ImageBuffer {
@@ -60,6 +61,7 @@ class PathTracer {
 
   // Components (pathtracer.h:87-97): the device context stands in for bvh
   ptamd_context *bvh = nullptr;
+  MultiGpu *multi = nullptr;  // several GPUs: the renderer's (see RaytracedRenderer::set_devices)
   ptamd_scene *scene = nullptr;
   const ptamd_camera *camera = nullptr;
   HDRImageBuffer sampleBuffer;
@@ -70,6 +72,10 @@ class PathTracer {
 
 class RaytracedRenderer {
  public:
+  // Render on several GPUs of this node (the counterpart of num_threads workers): call before
+  // set_scene. Loads libptamd_multi.so (and with it RCCL) from the directory of libptamd.so.
+  bool set_devices(const std::vector<int> &device_ids);
+
   enum State { INIT, READY, VISUALIZE, RENDERING, DONE };
 
   RaytracedRenderer(size_t ns_aa = 1, size_t max_ray_depth = 4, bool is_accumulate_bounces = false,
@@ -95,6 +101,7 @@ class RaytracedRenderer {
 
   PathTracer *pt;
   ptamd_context *bvh = nullptr;  // the device context holds the flattened BVH
+  MultiGpu *multi = nullptr;     // set_devices with more than one GPU: the GPUs' contexts instead of bvh
   ptamd_scene *scene = nullptr;
   const ptamd_camera *camera = nullptr;
   ImageBuffer frameBuffer;

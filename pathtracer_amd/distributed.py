@@ -1,18 +1,20 @@
 """Frame rendering in rounds, optionally sharded over the GPUs of one node.
 
 One process per GPU (``torch.distributed``, backend "nccl" = RCCL over xGMI). The
-scene is replicated; every round the still-active pixels are dealt out again,
-pixel ``active[k]`` going to rank ``k % world``. That is the dynamic load
-balancing: the reference's tile queue (src/util/work_queue.h:11-51,
-src/pathtracer/raytraced_renderer.cpp:297-302, 644-658) balances by handing
-tiles to idle threads; here the work list itself is re-dealt at pixel
-granularity after every adaptive-sampling round, so expensive pixels are spread
-evenly and no rank idles while another finishes a hard tile.
+scene is replicated and the pixels are dealt out, pixel ``list[k]`` going to rank
+``k % world``: the reference's tile queue (src/util/work_queue.h:11-51,
+src/pathtracer/raytraced_renderer.cpp:297-302, 644-658) balances by handing 32x32
+tiles to idle threads; dealing single pixels round-robin spreads the expensive regions of
+a frame evenly over the ranks to begin with. Two ways of doing it (`exchange`):
 
-After a round each rank owns the updated sums of its pixels; one all-gather
-replicates them, so every rank holds the whole frame state (s1, s2, sum, n per
-pixel) and computes the same next work list. The frame buffer is therefore
-assembled incrementally by RCCL and needs no final gather.
+"frame" (default): the frame's pixels are dealt ONCE. Every rank runs the whole adaptive
+  loop on its own pixels, with no communication inside the frame, and one all-gather of the
+  per-pixel sums at the end assembles the frame on every rank. Neighbouring pixels cost
+  about the same, so the ranks' loads agree to a percent or so without re-dealing.
+"round": the still-active pixels are dealt again after every adaptive round and one
+  all-gather per round replicates the updated sums, so every rank holds the whole frame
+  state and computes the same next work list. Exact balance in every round, at the price of
+  a collective (and a wait for the slowest rank) per round.
 
 Nothing in the loop waits for the GPU: the list lengths live in device memory
 and the kernels read them there (see render_frame).
@@ -69,8 +71,25 @@ class PixelSchedule:
         return max(int(k), 1)
 
 
+def per_pixel_default(params):
+    """Per-pixel look-ahead pays when a pixel may run for many batches (measured: 1024 spp in
+    batches of 32: 1 to 17 % faster, more so the smaller a rank's share; 256 spp: 3 to 10 % slower)."""
+    return params.ns_aa >= 16 * max(1, params.samples_per_batch)
+
+
+def _all_gather_rows(dist, recv, send, group, on_gpu):
+    if on_gpu and dist.get_backend(group) == "gloo":
+        # rehearsal without RCCL (several ranks sharing one GPU): stage through the host
+        got = torch.empty(recv.shape, dtype=recv.dtype)
+        dist.all_gather_into_tensor(got, send.cpu(), group=group)
+        recv.copy_(got)
+    else:
+        dist.all_gather_into_tensor(recv, send, group=group)
+
+
 def render_frame(dev, params, rank=0, world=1, group=None, device=None, record_rounds=None, lag=1,
-                 pixel_stride=1, target_paths=16 << 20, max_batches=32, per_pixel=False, sync_below=None):
+                 pixel_stride=1, target_paths=16 << 20, max_batches=32, per_pixel=None, sync_below=None,
+                 exchange="frame", pixel_offset=0):
     """Renders one frame; returns (hdr[h,w,3], count[h,w]) as tensors on `device`, on every rank.
 
     dev: api.Device with scene and camera set. With world > 1 the default process
@@ -92,14 +111,16 @@ def render_frame(dev, params, rank=0, world=1, group=None, device=None, record_r
     target_paths, max_batches: see PixelSchedule.batches (max_batches = 1 keeps to
     one batch per round, the reference's own cadence).
 
-    per_pixel: every pixel continues from its own sample count and is traced ahead
+    exchange: "frame" or "round", see the module's description (only matters with world > 1).
+
+    per_pixel (default: per_pixel_default(params)): every pixel continues from its own sample count and is traced ahead
     only as far as its running statistics predict it will need (trace_list with
     sample_base = -1), instead of all pixels of a round moving in lockstep. Same
     frame; fewer samples traced and then dropped when a rank's rounds are small.
 
-    pixel_stride = K renders only every K-th pixel of the rectangle (the others stay
-    black): one GPU then does the work one rank of K would do, which is how the
-    strong-scaling behaviour is rehearsed on a single GPU.
+    pixel_stride = K (with pixel_offset = r < K) renders only pixels r, r + K, r + 2K ... of the
+    rectangle (the others stay black): one GPU then does the work rank r of K would do with
+    exchange = "frame", which is how the strong-scaling behaviour is rehearsed on a single GPU.
     """
     import torch.distributed as dist
     w, h = params.w, params.h
@@ -112,7 +133,20 @@ def render_frame(dev, params, rank=0, world=1, group=None, device=None, record_r
     x1, y1 = min(w, params.x1), min(h, params.y1)
     ys = torch.arange(y0, y1, device=device, dtype=torch.int32)
     xs = torch.arange(x0, x1, device=device, dtype=torch.int32)
-    bufs = [(ys[:, None] * w + xs[None, :]).reshape(-1)[::max(1, pixel_stride)].contiguous(), None]
+    if per_pixel is None:
+        per_pixel = per_pixel_default(params)
+    if exchange not in ("frame", "round"):
+        raise ValueError("exchange must be 'frame' or 'round'")
+    all_pix = (ys[:, None] * w + xs[None, :]).reshape(-1)[pixel_offset::max(1, pixel_stride)].contiguous()
+    n_all = all_pix.numel()
+    deal_once = world > 1 and exchange == "frame"
+    if deal_once:
+        # this rank's pixels for the whole frame; the loop below then runs as a single rank would
+        frame_rank, frame_world = rank, world
+        bufs = [all_pix[rank::world].contiguous(), None]
+        rank, world = 0, 1
+    else:
+        bufs = [all_pix, None]
     bufs[1] = torch.empty_like(bufs[0])
     n0 = bufs[0].numel()
     n_dev = torch.full((2,), n0, dtype=torch.int64, device=device)  # lengths of bufs[0], bufs[1]
@@ -167,15 +201,20 @@ def render_frame(dev, params, rank=0, world=1, group=None, device=None, record_r
             m = PixelSchedule.padded(bound, world)
             send, recv = rows_send[:m], rows_recv[:world * m]
             dev.pack_rows(mine, state.data_ptr(), send.data_ptr(), stream)
-            if on_gpu and dist.get_backend(group) == "gloo":
-                # rehearsal without RCCL (several ranks sharing one GPU): stage through the host
-                got = torch.empty(recv.shape, dtype=recv.dtype)
-                dist.all_gather_into_tensor(got, send.cpu(), group=group)
-                recv.copy_(got)
-            else:
-                dist.all_gather_into_tensor(recv, send, group=group)
+            _all_gather_rows(dist, recv, send, group, on_gpu)
             dev.unpack_rows(whole, world, rank, recv.data_ptr(), m, state.data_ptr(), stream)
         done += batch if per_pixel else ns
+    if deal_once and n_all > 0:
+        # the one exchange of the frame: every rank's finished rows to every rank
+        n_all_dev = torch.full((1,), n_all, dtype=torch.int64, device=device)
+        whole = cabi.PixelList(all_pix.data_ptr(), n_all_dev.data_ptr(), 0, n_all, 0, 1)
+        mine = cabi.PixelList(all_pix.data_ptr(), n_all_dev.data_ptr(), 0, n_all, frame_rank, frame_world)
+        m = PixelSchedule.padded(n_all, frame_world)
+        send = torch.zeros((m, 6), dtype=torch.float64, device=device)
+        recv = torch.empty((frame_world * m, 6), dtype=torch.float64, device=device)
+        dev.pack_rows(mine, state.data_ptr(), send.data_ptr(), stream)
+        _all_gather_rows(dist, recv, send, group, on_gpu)
+        dev.unpack_rows(whole, frame_world, frame_rank, recv.data_ptr(), m, state.data_ptr(), stream)
     hdr = torch.empty(npix * 3, dtype=torch.float64, device=device)
     cnt = torch.empty(npix, dtype=torch.int32, device=device)
     dev.frame_resolve(state.data_ptr(), hdr.data_ptr(), cnt.data_ptr(), stream)

@@ -151,15 +151,18 @@ def _worker_body(rank, world, port, q):
     rounds = []
     cpu = torch.device("cpu")
     hdr, cnt = distributed.render_frame(dev, p, rank=rank, world=world, device=cpu, record_rounds=rounds, lag=0,
-                                        max_batches=1)
+                                        max_batches=1, per_pixel=False, exchange="round")
     traced = dev.traced
     # the pipelined schedule (bounds one round old) must give the same frame, and so
     # must rounds that trace several batches ahead of their adaptive tests
     for kw in (dict(lag=1, max_batches=1, sync_below=0), dict(lag=1), dict(lag=0, max_batches=2),
                dict(lag=1, per_pixel=True, sync_below=0), dict(lag=1, per_pixel=True),
                dict(lag=0, max_batches=2, per_pixel=True)):
-        hdr_l, cnt_l = distributed.render_frame(dev, p, rank=rank, world=world, device=cpu, **kw)
-        assert torch.equal(hdr_l, hdr) and torch.equal(cnt_l, cnt), "%r: frame differs" % (kw,)
+        kw.setdefault("per_pixel", False)
+        for exchange in ("round", "frame"):
+            # "frame": the pixels dealt once, no collective inside the frame, one all-gather at its end
+            hdr_l, cnt_l = distributed.render_frame(dev, p, rank=rank, world=world, device=cpu, exchange=exchange, **kw)
+            assert torch.equal(hdr_l, hdr) and torch.equal(cnt_l, cnt), "%r, exchange %s: frame differs" % (kw, exchange)
     q.put((rank, hdr.numpy().copy(), cnt.numpy().copy(), rounds, traced))
     dist.barrier()
     dist.destroy_process_group()
@@ -180,15 +183,15 @@ def test_two_ranks_equal_one_rank_bit_for_bit():
     one = OracleDevice(sc, cam)
     rounds1 = []
     hdr1, cnt1 = distributed.render_frame(one, p, device=torch.device("cpu"), record_rounds=rounds1, lag=0,
-                                          max_batches=1)
+                                          max_batches=1, per_pixel=False)
     hdr1, cnt1 = hdr1.numpy(), cnt1.numpy()
     rounds_l = []
     hdr_l, cnt_l = distributed.render_frame(one, p, device=torch.device("cpu"), record_rounds=rounds_l, lag=1,
-                                            max_batches=1, sync_below=0)  # (every bound lagged, however short the list)
+                                            max_batches=1, sync_below=0, per_pixel=False)  # (every bound lagged, however short the list)
     assert np.array_equal(hdr_l.numpy(), hdr1) and np.array_equal(cnt_l.numpy(), cnt1)
     # several batches per round, traced ahead of the adaptive tests: same frame, fewer rounds
     rounds_s = []
-    hdr_s, cnt_s = distributed.render_frame(one, p, device=torch.device("cpu"), record_rounds=rounds_s, lag=0)
+    hdr_s, cnt_s = distributed.render_frame(one, p, device=torch.device("cpu"), record_rounds=rounds_s, lag=0, per_pixel=False)
     assert np.array_equal(hdr_s.numpy(), hdr1) and np.array_equal(cnt_s.numpy(), cnt1)
     assert len(rounds_s) < len(rounds1)
     # with lag 1 the host's bound of round r is the exact count of round r - 1

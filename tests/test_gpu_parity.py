@@ -233,6 +233,7 @@ def test_errors_are_reported_not_fatal(device):
 # against outputs of the reference itself (tests/golden, see tools/make_golden.py)
 import hashlib
 import os
+import subprocess
 import sys
 
 from conftest import GOLDEN
@@ -384,3 +385,140 @@ def test_deep_bvh_spills_the_lane_stack(device):
     rh, rc, _ = O.render(arr, cam, p, threads=8)
     assert (cnt == rc).mean() >= 0.999
     assert np.isclose(hdr, rh, rtol=1e-9, atol=1e-12).all(axis=2).mean() >= 0.999
+
+
+def test_cpp_multi_gpu_driver_with_one_gpu_equals_render(device):
+    """ptamd_multi_* (C++ host threads + RCCL, libptamd_multi.so) with a single GPU: the same deal,
+    adaptive loop and resolve as with several, no exchange; equal to ptamd_render bit for bit."""
+    sc = pt.Scene(scene_path("CBspheres_lambertian"))
+    w, h = 96, 72
+    cam = sc.camera(w, h)
+    p = cabi.make_params(w, h, ns_aa=64, max_ray_depth=4, ns_area_light=2, seed=21)
+    device.upload(sc)
+    device.set_camera(cam)
+    hdr, cnt = device.render(p)
+    md = pt.MultiDevice([0])
+    md.upload(sc)
+    md.set_camera(cam)
+    for params in (p, cabi.make_params(w, h, ns_aa=64, max_ray_depth=4, ns_area_light=2, seed=21, rect=(10, 5, 50, 40))):
+        a, ac = md.render(params)
+        b, bc = device.render(params)
+        assert np.array_equal(ac, bc) and np.array_equal(a, b)
+    assert md.stats(0).samples == int(bc.sum())
+    md.close()
+    assert np.array_equal(device.render(p)[0], hdr)
+
+
+def _read_png_rgba(path):
+    """Minimal PNG reader for the encoder's own output (8-bit RGBA, no interlace)."""
+    import struct
+    import zlib
+    raw = open(path, "rb").read()
+    assert raw[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, idat, w, h = 8, b"", 0, 0
+    while pos < len(raw):
+        n, kind = struct.unpack(">I4s", raw[pos:pos + 8])
+        body = raw[pos + 8:pos + 8 + n]
+        if kind == b"IHDR":
+            w, h, depth, ctype, _, _, inter = struct.unpack(">IIBBBBB", body)
+            assert (depth, ctype, inter) == (8, 6, 0)
+        elif kind == b"IDAT":
+            idat += body
+        pos += 12 + n
+    data = zlib.decompress(idat)
+    stride = 4 * w
+    out = np.zeros((h, stride), np.uint8)
+    prev = np.zeros(stride, np.int32)
+    for y in range(h):
+        f = data[y * (stride + 1)]
+        line = np.frombuffer(data, np.uint8, stride, y * (stride + 1) + 1).astype(np.int32)
+        if f == 0:
+            cur = line
+        elif f == 2:
+            cur = (line + prev) & 255
+        else:  # sub / average / paeth: byte-serial
+            cur = np.zeros(stride, np.int32)
+            for i in range(stride):
+                a = cur[i - 4] if i >= 4 else 0
+                b = prev[i]
+                c = prev[i - 4] if i >= 4 else 0
+                if f == 1:
+                    pr = a
+                elif f == 3:
+                    pr = (a + b) // 2
+                else:
+                    pa, pb, pc = abs(b - c), abs(a - c), abs(a + b - 2 * c)
+                    pr = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+                cur[i] = (line[i] + pr) & 255
+        out[y] = cur
+        prev = cur
+    return out.reshape(h, w, 4)
+
+
+def _camera_settings_line(cam, w, h):
+    """A camera settings file (the layout of Camera::dump_settings, camera.cpp:151-166) for the
+    scene's own camera moved sideways: what matters to a render are the fields of view, the clip
+    distances, the position, c2w and the screen size."""
+    pos = [cam.pos[0] + 0.25, cam.pos[1] + 0.125, cam.pos[2] - 0.5]
+    rows = [cam.c2w[3 * c + r] for r in range(3) for c in range(3)]  # the file holds c2w row by row
+    lines = ["%r %r %r %r %r" % (cam.hFov, cam.vFov, w / h, cam.nClip, cam.fClip),
+             " ".join(repr(v) for v in pos + [0.0, 0.75, 0.0]),
+             "1.5 0.1 5.0 0.5 50.0",
+             " ".join(repr(v) for v in rows),
+             "%d %d 1.0" % (w, h),
+             "4.7 0.0"]
+    return "\n".join(lines) + "\n"
+
+
+def test_cpp_host_path_writes_the_frame_the_device_renders(device, tmp_path):
+    """The C++ host side (pathtracer_amd/bin/pathtracer: main.cpp + RaytracedRenderer + PathTracer over
+    the C ABI) end to end: its PNG is tonemap(device.render(...)) flipped, byte for byte; so are a
+    cell render (-p) and a render from a camera settings file (-c); the sampling-rate image is the
+    one ptamd_sampling_rate_rgba8 gives for the frame's sample counts."""
+    exe = os.path.join(os.path.dirname(GOLDEN), "..", "pathtracer_amd", "bin", "pathtracer")
+    scene = scene_path("CBspheres_lambertian")
+    w, h = 120, 90
+    out = str(tmp_path / "out.png")
+    r = subprocess.run([exe, "-s", "64", "-l", "4", "-m", "5", "-r", str(w), str(h), "-f", out, scene],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    sc = pt.Scene(scene)
+    device.upload(sc)
+    device.set_camera(sc.camera(w, h))
+    p = cabi.make_params(w, h, ns_aa=64, max_ray_depth=5, ns_area_light=4)
+    hdr, cnt = device.render(p)
+    rgba = pt.api.tonemap(hdr)
+    expect = rgba[::-1].copy().view(np.uint8).reshape(h, w, 4)
+    expect[..., 3] = 255
+    got = _read_png_rgba(out)
+    assert np.array_equal(got, expect)
+    # the sampling-rate image next to it (save_sampling_rate_image)
+    rate = _read_png_rgba(out[:-4] + "_rate.png")
+    exp_rate = pt.api.sampling_rate(cnt, 64).view(np.uint8).reshape(h, w, 4)
+    assert np.array_equal(rate, exp_rate)
+    # a cell: -p x y dx dy renders the rectangle only and writes it alone
+    cell = str(tmp_path / "cell.png")
+    r = subprocess.run([exe, "-s", "64", "-l", "4", "-m", "5", "-r", str(w), str(h), "-p", "30", "20", "40", "32",
+                        "-f", cell, scene], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    hdr_c, _ = device.render(cabi.make_params(w, h, ns_aa=64, max_ray_depth=5, ns_area_light=4, rect=(30, 20, 70, 52)))
+    exp_c = pt.api.tonemap(hdr_c)[20:52, 30:70][::-1].copy().view(np.uint8).reshape(32, 40, 4)
+    exp_c[..., 3] = 255
+    assert np.array_equal(_read_png_rgba(cell), exp_c)
+    # a camera settings file (-c), in the format Camera::dump_settings writes (camera.cpp:151-166)
+    sc2 = pt.Scene(scene)
+    cam0 = sc2.camera(w, h)
+    settings = str(tmp_path / "cam.txt")
+    vals = _camera_settings_line(cam0, w, h)
+    open(settings, "w").write(vals)
+    camfile = str(tmp_path / "cam.png")
+    r = subprocess.run([exe, "-s", "32", "-l", "2", "-m", "3", "-r", str(w), str(h), "-c", settings, "-f", camfile, scene],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    sc2.load_camera_file(settings)
+    device.upload(sc2)
+    device.set_camera(sc2.camera(0, 0))
+    hdr2, _ = device.render(cabi.make_params(w, h, ns_aa=32, max_ray_depth=3, ns_area_light=2))
+    exp2 = pt.api.tonemap(hdr2)[::-1].copy().view(np.uint8).reshape(h, w, 4)
+    exp2[..., 3] = 255
+    assert np.array_equal(_read_png_rgba(camfile), exp2)

@@ -30,7 +30,8 @@ def test_render_frame_pipelined_equals_synchronous_equals_render(device):
     cuda = torch.device("cuda", 0)
     # the reference's cadence: one batch per round, every count read before it is used
     base_rounds = []
-    hdr_b, cnt_b = distributed.render_frame(device, p, device=cuda, lag=0, max_batches=1, record_rounds=base_rounds)
+    hdr_b, cnt_b = distributed.render_frame(device, p, device=cuda, lag=0, max_batches=1, record_rounds=base_rounds,
+                                            per_pixel=False)
     hdr_b, cnt_b = hdr_b.cpu().numpy(), cnt_b.cpu().numpy()
     assert W * H * 16 < cnt_b.sum() < W * H * 96, "the adaptive test must stop some pixels early"
     assert len(base_rounds) == 6
@@ -107,6 +108,26 @@ def test_virtual_ranks_reproduce_the_single_gpu_frame(device, world, lag, max_ba
     p = _setup(device)
     hdr_r, cnt_r = device.render(p)
     hdr, cnt = _virtual_ranks_frame(device, p, world, lag, max_batches, per_pixel=per_pixel)
+    assert np.array_equal(cnt, cnt_r) and np.array_equal(hdr, hdr_r)
+
+
+@pytest.mark.parametrize("world,kw", [(2, dict(per_pixel=False)), (3, dict(per_pixel=True)),
+                                      (8, dict(per_pixel=False, max_batches=16)), (8, dict(per_pixel=True, lag=0))])
+def test_pixels_dealt_once_per_frame_reproduce_the_single_gpu_frame(device, world, kw):
+    """exchange = "frame": rank r renders pixels r, r + world, ... through the whole adaptive loop
+    on its own; the ranks' frames (played in turn on one GPU, the other pixels black) add up
+    to the single-GPU frame, bit for bit."""
+    p = _setup(device)
+    cuda = torch.device("cuda", 0)
+    hdr_r, cnt_r = device.render(p)
+    hdr = np.zeros_like(hdr_r)
+    cnt = np.zeros_like(cnt_r)
+    for r in range(world):
+        h_, c_ = distributed.render_frame(device, p, device=cuda, pixel_stride=world, pixel_offset=r, **kw)
+        h_, c_ = h_.cpu().numpy(), c_.cpu().numpy()
+        assert not (cnt[c_ > 0]).any(), "two ranks rendered the same pixel"
+        hdr += h_
+        cnt += c_
     assert np.array_equal(cnt, cnt_r) and np.array_equal(hdr, hdr_r)
 
 

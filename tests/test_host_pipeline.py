@@ -39,10 +39,27 @@ def _dump(name, w, h):
 def test_library_exports_every_declared_symbol():
     header = open(os.path.join(ROOT, "include", "ptamd.h")).read()
     declared = set(re.findall(r"\b(ptamd_[a-z0-9_]+)\s*\(", header))
-    assert declared == set(pt.api.EXPORTS), declared ^ set(pt.api.EXPORTS)
+    assert declared == set(pt.api.EXPORTS) | set(pt.api.EXPORTS_MULTI), declared ^ (set(pt.api.EXPORTS) | set(pt.api.EXPORTS_MULTI))
     L = pt.lib()
-    for s in declared:
+    for s in pt.api.EXPORTS:
         assert getattr(L, s) is not None
+    M = pt.lib_multi()  # several GPUs of a node: its own library (it links RCCL)
+    for s in pt.api.EXPORTS_MULTI:
+        assert getattr(M, s) is not None
+
+
+def test_multi_gpu_deal_arithmetic():
+    """The C++ multi-GPU driver's shares (pixel k of the rectangle to GPU k % n) agree with the
+    Python driver's schedule and cover every pixel once."""
+    from pathtracer_amd.distributed import PixelSchedule
+    M = pt.lib_multi()
+    for n in (0, 1, 2, 7, 8, 63, 480000, 480001, 2073600):
+        for world in (1, 2, 3, 4, 8):
+            sizes = [M.ptamd_multi_shard_size(n, r, world) for r in range(world)]
+            assert sizes == [PixelSchedule.shard_size(n, r, world) for r in range(world)]
+            assert sum(sizes) == n and max(sizes) - min(sizes) <= 1
+            assert M.ptamd_multi_rows_per_rank(n, world) == PixelSchedule.padded(n, world) == (max(sizes) if n else 0)
+    assert M.ptamd_multi_shard_size(10, 3, 3) == 0 and M.ptamd_multi_shard_size(10, -1, 3) == 0
 
 
 @pytest.mark.parametrize("name", LOCAL)

@@ -522,3 +522,31 @@ def test_cpp_host_path_writes_the_frame_the_device_renders(device, tmp_path):
     exp2 = pt.api.tonemap(hdr2)[::-1].copy().view(np.uint8).reshape(h, w, 4)
     exp2[..., 3] = 255
     assert np.array_equal(_read_png_rgba(camfile), exp2)
+
+
+def test_reference_host_code_with_the_device_layer_dropped_in(device, tmp_path):
+    """The drop-in, executed: oracle/_ref/ref_driver_dropin is the reference's own loader, scene
+    objects, BVH build, camera and RaytracedRenderer, compiled unmodified, with start_raytracing
+    replaced by the binding of oracle/dropin_glue.cpp (flatten what the reference built,
+    ptamd_upload_scene, ptamd_render). Its frame must equal, bit for bit, the frame this
+    repository's own host pipeline renders for the same command line."""
+    from pathtracer_amd import ptar
+    exe = os.path.join(os.path.dirname(GOLDEN), "..", "oracle", "_ref", "ref_driver_dropin")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/ref_driver_dropin is not built (make -C oracle dropin needs the reference checkout)")
+    for name, w, h, args, kw in (
+            ("CBspheres_lambertian", 120, 90, ["-s", "64", "-l", "4", "-m", "5"], dict(ns_aa=64, ns_area_light=4, max_ray_depth=5)),
+            ("CBbunny", 100, 75, ["-s", "32", "-l", "2", "-m", "3"], dict(ns_aa=32, ns_area_light=2, max_ray_depth=3))):
+        out = str(tmp_path / (name + ".ptar"))
+        r = subprocess.run([exe, "render"] + args + ["-t", "1", "-r", str(w), str(h), "-f", out, scene_path(name)],
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        a = ptar.load(out)
+        sc = pt.Scene(scene_path(name))
+        device.upload(sc)
+        device.set_camera(sc.camera(w, h))
+        hdr, cnt = device.render(cabi.make_params(w, h, **kw))
+        assert np.array_equal(a["count"].reshape(h, w), cnt)
+        assert np.array_equal(a["hdr"].reshape(h, w, 3), hdr)
+        # and the reference's own toColor on that frame gives the bytes of ptamd_tonemap_rgba8
+        assert np.array_equal(a["rgba8"].reshape(h, w).view(np.uint32), pt.api.tonemap(hdr))

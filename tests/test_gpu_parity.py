@@ -53,6 +53,10 @@ CASES = [
     ("CBgems", 64, 48, dict(ns_aa=32, max_ray_depth=4, ns_area_light=2)),
     ("CBbunny", 80, 60, dict(ns_aa=32, max_ray_depth=5, ns_area_light=4)),
     ("cube", 48, 36, dict(ns_aa=16, max_ray_depth=3, ns_area_light=2)),
+    # scenes lit by the other light kinds: a directional and three ambient (infinite-hemisphere)
+    # lights; a point and an ambient light
+    ("banana", 48, 36, dict(ns_aa=16, max_ray_depth=3, ns_area_light=2)),
+    ("plane", 48, 36, dict(ns_aa=16, max_ray_depth=2, ns_area_light=2)),
     ("CBspheres_lambertian", 64, 48, dict(ns_aa=32, max_ray_depth=3, ns_area_light=4, hemisphere=True)),
     ("CBspheres_lambertian", 64, 48, dict(ns_aa=32, max_ray_depth=2, ns_area_light=2, hemisphere=True, accumulate_bounces=False)),
     ("CBempty", 64, 48, dict(ns_aa=32, max_ray_depth=4, ns_area_light=4)),
@@ -84,7 +88,7 @@ def test_render_matches_oracle(device, name, w, h, kw):
     # (src/pathtracer/sampler.cpp:35-49); the device's and glibc's float routines differ in
     # the last bit, so with -H (and the infinite hemisphere light) directions agree to
     # ~1e-7 only, and a grazing sample can change sides of an edge.
-    float_trig = bool(kw.get("hemisphere"))
+    float_trig = bool(kw.get("hemisphere")) or bool((arr.a["light_kind"] == 1).any())
     rtol, share = (2e-5, 0.97) if float_trig else (1e-9, 0.999)
     assert same_cnt >= share, "sample-count maps differ on %.3f%% of pixels" % (100 * (1 - same_cnt))
     close = np.isclose(hdr, rh, rtol=rtol, atol=1e-12).all(axis=2)
@@ -301,7 +305,7 @@ def test_converged_image_agrees_with_reference_at_1024spp(device):
 def test_benchmark_configurations_agree_with_the_reference(device, tag, name, w, h, kw):
     """The five configurations of the benchmark table at full size, against the
     reference's own render of the same command line (8x8 block means, sample counts).
-    Different random numbers, so the bar is statistical: block means within 2 % relative
+    Different random numbers, so the bar is statistical: block means within 1 % relative
     L2 (they still carry 1/8 of the pixel noise at these sample counts), channel means
     within 0.5 %, total sample count within 2 %, block means of the sample-count map within
     5 % or within this implementation's own seed-to-seed distance."""
@@ -319,7 +323,11 @@ def test_benchmark_configurations_agree_with_the_reference(device, tag, name, w,
     ref = g["hdr_blocks"].astype(np.float64)
     noise = _rel_l2(_blocks(b), _blocks(a))
     d = _rel_l2(_blocks(a), ref)
-    assert d < 0.02 and d <= 1.5 * noise + 0.002, (d, noise)
+    print("%s: block-mean relative L2 to the reference's render %.5f (seed to seed %.5f), samples %d vs %d" % (
+        tag, d, noise, int(ac.sum()), int(g["total_samples"])))
+    # the bar: below 1 % (observed: 0.33 %, 0.21 %, 0.17 %, ... , 0.16 % for configurations 1 to 5, about
+    # what two renders of this implementation with different seeds differ by)
+    assert d < 0.01 and d <= 1.5 * noise + 0.002, (d, noise)
     assert abs(int(ac.sum()) - int(g["total_samples"])) < 0.02 * int(g["total_samples"])
     for c in range(3):
         assert abs(a[..., c].mean() - g["mean_rgb"][c]) < 0.005 * g["mean_rgb"][c]
@@ -550,3 +558,31 @@ def test_reference_host_code_with_the_device_layer_dropped_in(device, tmp_path):
         assert np.array_equal(a["hdr"].reshape(h, w, 3), hdr)
         # and the reference's own toColor on that frame gives the bytes of ptamd_tonemap_rgba8
         assert np.array_equal(a["rgba8"].reshape(h, w).view(np.uint32), pt.api.tonemap(hdr))
+
+
+@pytest.mark.parametrize("tag,name,kw", [
+    ("cube_64x48", "cube", dict(ns_aa=256, ns_area_light=1, max_ray_depth=3)),        # point light
+    ("banana_64x48", "banana", dict(ns_aa=256, ns_area_light=2, max_ray_depth=3)),    # directional + 3 ambient lights
+    ("plane_64x48", "plane", dict(ns_aa=256, ns_area_light=2, max_ray_depth=2)),      # point + ambient light
+])
+def test_non_area_lights_agree_with_the_reference(device, tag, name, kw):
+    """Point, directional and infinite-hemisphere lights (src/scene/light.cpp:17-57) against the
+    reference's own renders of scenes that have them: 8x8 block means within 1 % relative L2 plus
+    the seed-to-seed noise of this implementation, channel means within 1 %, the same stop rate."""
+    w, h = 64, 48
+    g = np.load(os.path.join(GOLDEN, "render_%s.npz" % tag))
+    ref = g["hdr"].astype(np.float64).reshape(h, w, 3)
+    refc = g["count"].reshape(h, w)
+    sc = pt.Scene(scene_path(name))
+    device.upload(sc)
+    device.set_camera(sc.camera(w, h))
+    a, ac = device.render(cabi.make_params(w, h, seed=3, **kw))
+    b, _ = device.render(cabi.make_params(w, h, seed=4, **kw))
+    assert ref.max() > 0 and a.max() > 0
+    noise = _rel_l2(_blocks(b), _blocks(a))
+    d = _rel_l2(_blocks(a), _blocks(ref))
+    print("%s: block-mean distance to the reference %.4f, seed-to-seed %.4f" % (tag, d, noise))
+    assert d < 0.01 + 1.5 * noise, (d, noise)
+    ma, mr = a.reshape(-1, 3).mean(axis=0), ref.reshape(-1, 3).mean(axis=0)
+    assert np.all(np.abs(ma - mr) <= 0.01 * mr + 1e-6), (ma, mr)
+    assert abs(ac.mean() - refc.mean()) <= 0.03 * refc.mean() + 0.5

@@ -41,7 +41,15 @@ def test_tonemap_bit_exact():
 
 
 def _scene(name):
-    a = ptar.load(_g("scene_%s.ptar" % name))
+    path = _g("scene_%s.ptar" % name)
+    if not os.path.exists(path):
+        # no array dump of this scene in the fixtures: the product loader's arrays, which
+        # tests/test_host_pipeline.py shows to be the reference's bit for bit
+        import pathtracer_amd as pt
+        from conftest import scene_path
+        arr = pt.Scene(scene_path(name)).arrays()
+        return arr, arr.a
+    a = ptar.load(path)
     return cabi.SceneArrays.from_ptar(a), a
 
 
@@ -94,6 +102,10 @@ RENDERS = [
     ("cbsl_64x48_a16", "CBspheres_lambertian", 64, 48, dict(ns_aa=256, ns_area_light=1, max_ray_depth=4, samples_per_batch=16, max_tolerance=0.2)),
     ("cbspheres_96x72", "CBspheres", 96, 72, dict(ns_aa=256, ns_area_light=4, max_ray_depth=5)),
     ("cbgems_96x72", "CBgems", 96, 72, dict(ns_aa=256, ns_area_light=4, max_ray_depth=5)),
+    # point light; directional + three ambient (infinite-hemisphere) lights; point + ambient
+    ("cube_64x48", "cube", 64, 48, dict(ns_aa=256, ns_area_light=1, max_ray_depth=3)),
+    ("banana_64x48", "banana", 64, 48, dict(ns_aa=256, ns_area_light=2, max_ray_depth=3)),
+    ("plane_64x48", "plane", 64, 48, dict(ns_aa=256, ns_area_light=2, max_ray_depth=2)),
 ]
 
 

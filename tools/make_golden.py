@@ -52,10 +52,16 @@ def scenes():
     return out
 
 
-def main():
+def main(only_renders=False):
     os.makedirs(GOLD, exist_ok=True)
     os.makedirs(TMP, exist_ok=True)
     sc = scenes()
+    if not only_renders:
+        scene_and_primary_goldens(sc)
+    render_goldens(sc)
+
+
+def scene_and_primary_goldens(sc):
     run(["kat", "-f", os.path.join(GOLD, "kat.ptar")])
 
     hashes = {}
@@ -89,6 +95,9 @@ def main():
             rec["t_sub_%d" % o] = a["primary_t_%d" % o][::97]
         np.savez_compressed(os.path.join(GOLD, "primary_%s_%dx%d.npz" % (name, w, h)), **rec)
 
+
+
+def render_goldens(sc):
     renders = [
         # tag, scene, threads, args
         ("cbsl_120x90_s1024", "CBspheres_lambertian", 8, ["-s", "1024", "-l", "4", "-m", "5", "-r", "120", "90"]),
@@ -102,7 +111,14 @@ def main():
         ("cbspheres_96x72", "CBspheres", 4, ["-s", "256", "-l", "4", "-m", "5", "-r", "96", "72"]),
         ("cbgems_96x72", "CBgems", 4, ["-s", "256", "-l", "4", "-m", "5", "-r", "96", "72"]),
         ("cbbunny_100x75", "CBbunny", 8, ["-s", "256", "-l", "4", "-m", "5", "-r", "100", "75"]),
+        # the light kinds the Cornell boxes do not have: a point light (cube), a directional light and
+        # three ambient (infinite-hemisphere) lights (banana), a point and an ambient light (plane)
+        ("cube_64x48", "cube", 1, ["-s", "256", "-l", "1", "-m", "3", "-r", "64", "48"]),
+        ("banana_64x48", "banana", 1, ["-s", "256", "-l", "2", "-m", "3", "-r", "64", "48"]),
+        ("plane_64x48", "plane", 1, ["-s", "256", "-l", "2", "-m", "2", "-r", "64", "48"]),
     ]
+    if len(sys.argv) > 2 and sys.argv[1] == "renders":
+        renders = [r for r in renders if sys.argv[2] in r[0]]
     for tag, name, threads, args in renders:
         out = os.path.join(TMP, "r.ptar")
         t0 = time.time()
@@ -156,7 +172,10 @@ def block_goldens(only=None):
 if __name__ == "__main__":
     if not os.path.exists(REF):
         raise SystemExit("build the reference driver first: make -C oracle ref")
-    if len(sys.argv) > 1 and sys.argv[1] == "blocks":
+    if len(sys.argv) > 1 and sys.argv[1] == "renders":
+        os.makedirs(TMP, exist_ok=True)
+        main(only_renders=True)
+    elif len(sys.argv) > 1 and sys.argv[1] == "blocks":
         os.makedirs(TMP, exist_ok=True)
         block_goldens(sys.argv[2] if len(sys.argv) > 2 else None)
     else:

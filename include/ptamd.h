@@ -168,6 +168,8 @@ int ptamd_scene_get_desc(const ptamd_scene *scene, ptamd_scene_desc *out);
 int ptamd_scene_get_camera(ptamd_scene *scene, int32_t w, int32_t h, ptamd_camera *out);
 /* Replaces Camera::load_settings (camera.cpp:170-185), the -c option. */
 int ptamd_scene_load_camera_file(ptamd_scene *scene, const char *path);
+/* Camera::dump_settings (camera.cpp:151-168): the same file, written. */
+int ptamd_scene_dump_camera_file(ptamd_scene *scene, const char *path);
 /* BVH build wall time in seconds (what build_accel prints). */
 double ptamd_scene_build_seconds(const ptamd_scene *scene);
 

@@ -174,6 +174,8 @@ struct Args {
   size_t w = 0, h = 0;
   long cx = -1, cy = 0, cdx = 0, cdy = 0;  // -p cell
   std::string scene;
+  std::string cam_in, cam_out;  // -c: Camera::load_settings before anything else; -D: Camera::dump_settings
+  std::string png;  // -P: RaytracedRenderer::save_image writes the frame here (and its _rate.png)
 };
 
 RefApp *make_app(const Args &a) {
@@ -570,6 +572,8 @@ void dump_render(RefApp *app, FILE *f, const Args &a) {
   ptar_put(f, "stats", PTAR_F64, stats, 6);
   fprintf(stderr, "ref_driver: %lld samples in %.3f s = %.4g samples/s (%d threads)\n", total, secs,
           total / secs, (int)a.threads);
+  // the reference's own output stage: the PNG and its "_rate.png" (raytraced_renderer.cpp:680-751)
+  if (!a.png.empty()) R->save_image(a.png);
   // the worker threads are joined by stop() in the reference; leave them
   R->stop();
 }
@@ -577,7 +581,7 @@ void dump_render(RefApp *app, FILE *f, const Args &a) {
 void usage() {
   fprintf(stderr,
           "usage: ref_driver <dump|primary|render|kat> [-s spp -l light -m depth -o accum -t threads\n"
-          "                  -a batch tol -H -r W H -p x y dx dy] -f out.ptar [scene.dae]\n");
+          "                  -a batch tol -H -r W H -p x y dx dy -P frame.png -c cam_in.txt -D cam_out.txt] -f out.ptar [scene.dae]\n");
 }
 
 }  // namespace
@@ -590,7 +594,7 @@ int main(int argc, char **argv) {
   int opt;
   optind = 2;
   // same option letters and two-word handling as src/application/main.cpp:126-187
-  while ((opt = getopt(argc, argv, "s:l:t:m:o:f:r:a:Hp:")) != -1) {
+  while ((opt = getopt(argc, argv, "s:l:t:m:o:f:r:a:Hp:P:c:D:")) != -1) {
     switch (opt) {
       case 'f': out = optarg; break;
       case 'r': a.w = atoi(argv[optind - 1]); a.h = atoi(argv[optind]); optind++; break;
@@ -601,6 +605,9 @@ int main(int argc, char **argv) {
       case 'o': a.accum = atoi(optarg) > 0; break;
       case 'a': a.samples_per_batch = atoi(argv[optind - 1]); a.max_tolerance = atof(argv[optind]); optind++; break;
       case 'H': a.hemisphere = true; break;
+      case 'P': a.png = optarg; break;
+      case 'c': a.cam_in = optarg; break;
+      case 'D': a.cam_out = optarg; break;
       case 'p':
         a.cx = atoi(argv[optind - 1]); a.cy = atoi(argv[optind]);
         a.cdx = atoi(argv[optind + 1]); a.cdy = atoi(argv[optind + 2]);
@@ -620,6 +627,9 @@ int main(int argc, char **argv) {
   if (optind >= argc) { usage(); return 1; }
   a.scene = argv[optind];
   RefApp *app = make_app(a);
+  // main.cpp:220-224: the settings file is loaded after the resize
+  if (!a.cam_in.empty()) app->camera.load_settings(a.cam_in);
+  if (!a.cam_out.empty()) app->camera.dump_settings(a.cam_out);
   if (mode == "dump") {
     dump_scene(app, f);
   } else if (mode == "primary") {

@@ -12,7 +12,7 @@ _LIB = None
 
 # every symbol include/ptamd.h declares
 EXPORTS = (
-    "ptamd_last_error", "ptamd_scene_load", "ptamd_scene_free", "ptamd_scene_get_desc",
+    "ptamd_last_error", "ptamd_scene_load", "ptamd_scene_dump_camera_file", "ptamd_scene_free", "ptamd_scene_get_desc",
     "ptamd_scene_get_camera", "ptamd_scene_load_camera_file", "ptamd_scene_build_seconds",
     "ptamd_create", "ptamd_destroy", "ptamd_upload_scene", "ptamd_set_camera", "ptamd_set_max_paths",
     "ptamd_set_profiling", "ptamd_set_event_classes", "ptamd_render", "ptamd_trace_primary", "ptamd_frame_begin",
@@ -50,6 +50,7 @@ def lib():
     L.ptamd_scene_get_desc.argtypes = [vp, C.POINTER(SceneDesc)]
     L.ptamd_scene_get_camera.argtypes = [vp, i32, i32, C.POINTER(Camera)]
     L.ptamd_scene_load_camera_file.argtypes = [vp, C.c_char_p]
+    L.ptamd_scene_dump_camera_file.argtypes = [vp, C.c_char_p]
     L.ptamd_scene_build_seconds.argtypes = [vp]
     L.ptamd_scene_build_seconds.restype = dbl
     L.ptamd_create.argtypes = [i32, C.POINTER(vp)]
@@ -144,6 +145,9 @@ class Scene:
 
     def load_camera_file(self, path):
         _check(lib().ptamd_scene_load_camera_file(self._h, os.fsencode(path)))
+
+    def dump_camera_file(self, path):
+        _check(lib().ptamd_scene_dump_camera_file(self._h, os.fsencode(path)))
 
     def arrays(self):
         """Deep numpy copy of the flattened scene (cabi.SceneArrays)."""

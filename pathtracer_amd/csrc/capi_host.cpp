@@ -149,6 +149,12 @@ int ptamd_scene_load_camera_file(ptamd_scene *s, const char *path) {
   return PTAMD_OK;
 }
 
+int ptamd_scene_dump_camera_file(ptamd_scene *s, const char *path) {
+  if (!s || !path) { set_error("null argument"); return PTAMD_ERR_ARG; }
+  if (!s->S.camera.dump_settings(path)) { set_error(std::string("cannot write camera settings to ") + path); return PTAMD_ERR_IO; }
+  return PTAMD_OK;
+}
+
 double ptamd_scene_build_seconds(const ptamd_scene *s) { return s ? s->S.build_seconds : 0.0; }
 
 // HDRImageBuffer::toColor + ImageBuffer::update_pixel, src/util/image.h:183-198, 53-62

@@ -301,33 +301,69 @@ void CameraState::compute_position() {  // camera.cpp:123-146
   c2w.col[2] = unit(dirToCamera);
 }
 
-bool CameraState::load_settings(const std::string &filename) {  // camera.cpp:170-185
+// The camera settings file (written by Camera::dump_settings, read by Camera::load_settings,
+// src/pathtracer/camera.cpp:151-185) is 26 numbers separated by white space:
+//   hFov vFov ar nClip fClip | pos.xyz targetPos.xyz | phi theta r minR maxR |
+//   c2w row by row | screenW screenH screenDist | focalDistance lensRadius
+// Both directions go through one table of where each number lives, so that they cannot drift
+// apart. The thin-lens pair at the end is read and dropped (the reference's thin-lens camera is a
+// stub that raytrace_pixel never calls), and written as the reference's defaults.
+namespace {
+struct SettingsSlot {
+  double *d;     // a double field, or
+  size_t *z;     // a size_t field (the screen size), or neither: a value that is not kept
+  double spare;  // what is written for a value that is not kept
+  char after;    // the separator the reference writes after it: ' ' or '\n'
+};
+std::vector<SettingsSlot> settings_layout(CameraState &c) {
+  std::vector<SettingsSlot> t;
+  auto num = [&](double &x, char after = ' ') { t.push_back({&x, nullptr, 0.0, after}); };
+  num(c.hFov); num(c.vFov); num(c.ar); num(c.nClip); num(c.fClip, '\n');
+  for (int k = 0; k < 3; k++) num(c.pos[k]);
+  for (int k = 0; k < 3; k++) num(c.targetPos[k]);
+  t.back().after = 'N';  // the reference ends this line with " \n" (a space after every element)
+  num(c.phi); num(c.theta); num(c.r); num(c.minR); num(c.maxR, '\n');
+  for (int row = 0; row < 3; row++)
+    for (int col = 0; col < 3; col++) num(c.c2w.col[col][row]);
+  t.back().after = 'N';
+  t.push_back({nullptr, &c.screenW, 0.0, ' '});
+  t.push_back({nullptr, &c.screenH, 0.0, ' '});
+  num(c.screenDist, '\n');
+  t.push_back({nullptr, nullptr, 4.7, ' '});   // focalDistance
+  t.push_back({nullptr, nullptr, 0.0, '\n'});  // lensRadius
+  return t;
+}
+}  // namespace
+
+bool CameraState::load_settings(const std::string &filename) {
   std::ifstream file(filename);
   if (!file.is_open()) return false;
-  double focalDistance, lensRadius;
-  file >> hFov >> vFov >> ar >> nClip >> fClip;
-  for (int i = 0; i < 3; ++i) file >> pos[i];
-  for (int i = 0; i < 3; ++i) file >> targetPos[i];
-  file >> phi >> theta >> r >> minR >> maxR;
-  for (int i = 0; i < 9; ++i) file >> c2w.col[i % 3][i / 3];  // c2w(i/3, i%3): row i/3, column i%3
-  file >> screenW >> screenH >> screenDist;
-  file >> focalDistance >> lensRadius;
-  return !file.fail();
+  CameraState next = *this;  // a file that ends early leaves the camera as it was
+  for (const SettingsSlot &slot : settings_layout(next)) {
+    if (slot.z) {
+      file >> *slot.z;
+    } else {
+      double v = 0;
+      file >> v;
+      if (slot.d) *slot.d = v;
+    }
+    if (file.fail()) return false;
+  }
+  *this = next;
+  return true;
 }
 
-bool CameraState::dump_settings(const std::string &filename) const {  // camera.cpp:151-168
+bool CameraState::dump_settings(const std::string &filename) const {
   std::ofstream file(filename);
   if (!file.is_open()) return false;
-  file << hFov << " " << vFov << " " << ar << " " << nClip << " " << fClip << std::endl;
-  for (int i = 0; i < 3; ++i) file << pos[i] << " ";
-  for (int i = 0; i < 3; ++i) file << targetPos[i] << " ";
-  file << std::endl;
-  file << phi << " " << theta << " " << r << " " << minR << " " << maxR << std::endl;
-  for (int i = 0; i < 9; ++i) file << c2w.col[i % 3][i / 3] << " ";
-  file << std::endl;
-  file << screenW << " " << screenH << " " << screenDist << std::endl;
-  file << 4.7 << " " << 0.0 << std::endl;
-  return true;
+  CameraState copy = *this;
+  for (const SettingsSlot &slot : settings_layout(copy)) {
+    if (slot.z) file << *slot.z;
+    else file << (slot.d ? *slot.d : slot.spare);
+    if (slot.after == 'N') file << " \n";
+    else file << slot.after;
+  }
+  return (bool)file.flush();
 }
 
 // --------------------------------------------------------------------------- scene

@@ -417,50 +417,7 @@ def test_cpp_multi_gpu_driver_with_one_gpu_equals_render(device):
     assert np.array_equal(device.render(p)[0], hdr)
 
 
-def _read_png_rgba(path):
-    """Minimal PNG reader for the encoder's own output (8-bit RGBA, no interlace)."""
-    import struct
-    import zlib
-    raw = open(path, "rb").read()
-    assert raw[:8] == b"\x89PNG\r\n\x1a\n"
-    pos, idat, w, h = 8, b"", 0, 0
-    while pos < len(raw):
-        n, kind = struct.unpack(">I4s", raw[pos:pos + 8])
-        body = raw[pos + 8:pos + 8 + n]
-        if kind == b"IHDR":
-            w, h, depth, ctype, _, _, inter = struct.unpack(">IIBBBBB", body)
-            assert (depth, ctype, inter) == (8, 6, 0)
-        elif kind == b"IDAT":
-            idat += body
-        pos += 12 + n
-    data = zlib.decompress(idat)
-    stride = 4 * w
-    out = np.zeros((h, stride), np.uint8)
-    prev = np.zeros(stride, np.int32)
-    for y in range(h):
-        f = data[y * (stride + 1)]
-        line = np.frombuffer(data, np.uint8, stride, y * (stride + 1) + 1).astype(np.int32)
-        if f == 0:
-            cur = line
-        elif f == 2:
-            cur = (line + prev) & 255
-        else:  # sub / average / paeth: byte-serial
-            cur = np.zeros(stride, np.int32)
-            for i in range(stride):
-                a = cur[i - 4] if i >= 4 else 0
-                b = prev[i]
-                c = prev[i - 4] if i >= 4 else 0
-                if f == 1:
-                    pr = a
-                elif f == 3:
-                    pr = (a + b) // 2
-                else:
-                    pa, pb, pc = abs(b - c), abs(a - c), abs(a + b - 2 * c)
-                    pr = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
-                cur[i] = (line[i] + pr) & 255
-        out[y] = cur
-        prev = cur
-    return out.reshape(h, w, 4)
+from png_reader import read_png_rgba as _read_png_rgba
 
 
 def _camera_settings_line(cam, w, h):
@@ -546,7 +503,8 @@ def test_reference_host_code_with_the_device_layer_dropped_in(device, tmp_path):
             ("CBspheres_lambertian", 120, 90, ["-s", "64", "-l", "4", "-m", "5"], dict(ns_aa=64, ns_area_light=4, max_ray_depth=5)),
             ("CBbunny", 100, 75, ["-s", "32", "-l", "2", "-m", "3"], dict(ns_aa=32, ns_area_light=2, max_ray_depth=3))):
         out = str(tmp_path / (name + ".ptar"))
-        r = subprocess.run([exe, "render"] + args + ["-t", "1", "-r", str(w), str(h), "-f", out, scene_path(name)],
+        png = str(tmp_path / (name + ".png"))
+        r = subprocess.run([exe, "render"] + args + ["-t", "1", "-r", str(w), str(h), "-P", png, "-f", out, scene_path(name)],
                            capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stdout + r.stderr
         a = ptar.load(out)
@@ -558,6 +516,13 @@ def test_reference_host_code_with_the_device_layer_dropped_in(device, tmp_path):
         assert np.array_equal(a["hdr"].reshape(h, w, 3), hdr)
         # and the reference's own toColor on that frame gives the bytes of ptamd_tonemap_rgba8
         assert np.array_equal(a["rgba8"].reshape(h, w).view(np.uint32), pt.api.tonemap(hdr))
+        # the reference's save_image / save_sampling_rate_image (raytraced_renderer.cpp:680-751) wrote
+        # two PNGs from what the device returned: the pixels this library's output stage produces
+        expect = pt.api.tonemap(hdr)[::-1].copy().view(np.uint8).reshape(h, w, 4)
+        expect[..., 3] = 255
+        assert np.array_equal(_read_png_rgba(png), expect)
+        rate = pt.api.sampling_rate(cnt, kw["ns_aa"]).view(np.uint8).reshape(h, w, 4)
+        assert np.array_equal(_read_png_rgba(png[:-4] + "_rate.png"), rate)
 
 
 @pytest.mark.parametrize("tag,name,kw", [

@@ -187,3 +187,72 @@ def test_black_specular_spheres_like_the_reference():
     p = cabi.make_params(w, h, ns_aa=32, ns_area_light=2, max_ray_depth=5, seed=5)
     hdr, _, _ = O.render(sc, cam, p, threads=8)
     assert hdr[inner].max() == 0.0
+
+
+def test_output_stage_against_the_reference_png_writer(tmp_path):
+    """RaytracedRenderer::save_image and save_sampling_rate_image (raytraced_renderer.cpp:680-751),
+    run by the reference itself on a frame it rendered: the frame PNG holds the bytes
+    ptamd_tonemap_rgba8 gives for the reference's HDR buffer (flipped, alpha 255), the _rate.png
+    the colours ptamd_sampling_rate_rgba8 gives for its sample counts."""
+    import subprocess
+    import pathtracer_amd as pt
+    from conftest import ROOT, scene_path
+    from png_reader import read_png_rgba
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/ref_driver is not built")
+    w, h = 48, 36
+    out, png = str(tmp_path / "r.ptar"), str(tmp_path / "frame.png")
+    r = subprocess.run([exe, "render", "-s", "128", "-l", "2", "-m", "3", "-a", "16", "0.12", "-t", "1", "-r", str(w), str(h), "-P", png,
+                        "-f", out, scene_path("CBspheres_lambertian")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    a = ptar.load(out)
+    hdr = a["hdr"].reshape(h, w, 3)
+    cnt = a["count"].reshape(h, w)
+    assert 16 * w * h < cnt.sum() < 128 * w * h and len(np.unique(cnt)) > 2  # the rate image has several colours
+    expect = pt.api.tonemap(hdr)[::-1].copy().view(np.uint8).reshape(h, w, 4)
+    expect[..., 3] = 255
+    assert np.array_equal(read_png_rgba(png), expect)
+    rate = pt.api.sampling_rate(cnt, 128).view(np.uint8).reshape(h, w, 4)
+    assert np.array_equal(read_png_rgba(png[:-4] + "_rate.png"), rate)
+
+
+def test_camera_settings_file_against_the_reference(tmp_path):
+    """Camera::dump_settings / load_settings (camera.cpp:151-185), run by the reference: the file
+    it dumps for a scene's camera is byte for byte the file this library dumps, and a settings
+    file loaded by both gives the same camera (position, c2w, fields of view, clip distances)."""
+    import subprocess
+    import pathtracer_amd as pt
+    from conftest import ROOT, scene_path
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/ref_driver is not built")
+    w, h = 480, 360
+    scene = scene_path("CBspheres_lambertian")
+    ref_txt, out = str(tmp_path / "ref_cam.txt"), str(tmp_path / "d.ptar")
+    r = subprocess.run([exe, "dump", "-r", str(w), str(h), "-D", ref_txt, "-f", out, scene], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    sc = pt.Scene(scene)
+    sc.camera(w, h)
+    mine_txt = str(tmp_path / "mine_cam.txt")
+    sc.dump_camera_file(mine_txt)
+    assert open(mine_txt).read() == open(ref_txt).read()
+    # a hand-made file: another position, orientation and field of view
+    custom = str(tmp_path / "custom.txt")
+    open(custom, "w").write("41.5 30.25 1.3333 0.02 90\n0.5 1.25 3.5 0 0.75 0 \n1.2 0.3 4 0.1 40\n"
+                            "0.8 0 0.6 0 1 0 -0.6 0 0.8 \n480 360 468.25\n4.7 0\n")
+    out2 = str(tmp_path / "d2.ptar")
+    r = subprocess.run([exe, "dump", "-r", str(w), str(h), "-c", custom, "-f", out2, scene], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    ref_cam = cabi.camera_from_dump(ptar.load(out2)["camera"])
+    sc.load_camera_file(custom)
+    cam = sc.camera(0, 0)
+    for f in ("hFov", "vFov", "nClip", "fClip"):
+        assert getattr(cam, f) == getattr(ref_cam, f), f
+    assert list(cam.pos) == list(ref_cam.pos) == [0.5, 1.25, 3.5]
+    assert list(cam.c2w) == list(ref_cam.c2w)
+    assert list(cam.c2w)[:3] == [0.8, 0.0, -0.6]  # the file holds c2w row by row, the ABI column by column
+    with pytest.raises(pt.PtamdError):
+        open(custom, "w").write("41.5 30.25")  # a file that ends early is an error, the camera stays
+        sc.load_camera_file(custom)
+    assert list(sc.camera(0, 0).pos) == [0.5, 1.25, 3.5]

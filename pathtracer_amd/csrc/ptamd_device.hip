@@ -280,7 +280,7 @@ __device__ __forceinline__ RayF make_rayf(v3 d) {
 #define PTAMD_STACK_EXTEND 14  // 5 workgroups per CU x 30 KiB
 #endif
 #ifndef PTAMD_STACK_SHADOW
-#define PTAMD_STACK_SHADOW 12  // 6 workgroups per CU x 26 KiB
+#define PTAMD_STACK_SHADOW 10  // 7 workgroups per CU x 22 KiB
 #endif
 // Build-time tuning of the traversal kernels (defaults are the measured best):
 // resident waves per SIMD the register allocator must make room for (0: its own
@@ -292,6 +292,9 @@ __device__ __forceinline__ RayF make_rayf(v3 d) {
 #ifndef PTAMD_GRID_MULT
 #define PTAMD_GRID_MULT 8
 #endif
+#ifndef PTAMD_IN_ORDER
+#define PTAMD_IN_ORDER 1  // first-hit walks take a node's children in the node's order (see node_step)
+#endif
 #ifndef PTAMD_NODE_STEPS
 #define PTAMD_NODE_STEPS 2
 #endif
@@ -300,7 +303,7 @@ __device__ __forceinline__ RayF make_rayf(v3 d) {
 #define PTAMD_REFILL_EXTEND 24
 #endif
 #ifndef PTAMD_REFILL_SHADOW
-#define PTAMD_REFILL_SHADOW 48
+#define PTAMD_REFILL_SHADOW 40
 #endif
 #ifndef PTAMD_REFILL_TWO_S
 #define PTAMD_REFILL_TWO_S 40  // the shadow-ray list of k_trace2
@@ -309,7 +312,7 @@ __device__ __forceinline__ RayF make_rayf(v3 d) {
 #define PTAMD_WAVES_EXTEND 5  // the closest-hit walk with lane refill needs ~96 registers; spilling costs more than a wave
 #endif
 #ifndef PTAMD_WAVES_SHADOW
-#define PTAMD_WAVES_SHADOW PTAMD_WAVES_PER_EU
+#define PTAMD_WAVES_SHADOW 7  // first-hit walks: 72 registers, 4 of them spilled; 8 waves lose
 #endif
 #define TRAV_BOUNDS_N(n) __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(n, n)))
 constexpr int TRAV_BLOCK = 256;
@@ -466,8 +469,13 @@ struct Walk {
   }
 
   // cur >= 0: test the node's four child boxes, descend into the nearest
+  // in_order (the same for every lane of the wave): the accepted children are taken in the node's own
+  // order instead of nearest first. A first-hit walk of a ray that nothing occludes, the common
+  // shadow ray, visits every box the ray meets whatever the order, so ordering its children
+  // (a quarter of a box step's instructions) buys nothing.
   template <bool COUNT>
-  __device__ __forceinline__ void node_step(const DevScene &S, const TravStack &stack, uint32_t &n_nodes, float m0) {
+  __device__ __forceinline__ void node_step(const DevScene &S, const TravStack &stack, uint32_t &n_nodes, float m0,
+                                            bool in_order = false) {
     const float FINF = INFINITY;
     const uint4 *np = reinterpret_cast<const uint4 *>(S.nodes + cur);
     const uint4 w0 = np[0], w1 = np[1], w2 = np[2];
@@ -509,6 +517,26 @@ struct Walk {
       const float lo2 = fmaxf(fmaxf(fmaxf(tn[0], tn[1]), tn[2]), m0);
       const float hi2 = fminf(fminf(fminf(tf[0], tf[1]), tf[2]), best_f);
       t[k] = (c[k] != CHILD_EMPTY && !(lo2 > hi2)) ? lo2 : FINF;
+    }
+    if (in_order) {
+      const int a0 = t[0] < FINF, a1 = t[1] < FINF, a2 = t[2] < FINF, a3 = t[3] < FINF;
+      const int n01 = a0 + a1, n012 = n01 + a2, nacc = n012 + a3;
+      if (nacc == 0) { pop(stack); return; }
+      // the first accepted child is next; each later one goes on the stack, above those before it
+      const bool p1 = a1 && a0, p2 = a2 && n01 > 0, p3 = a3 && n012 > 0;
+      if (sp + 3 <= stack.STACK_LDS) {
+        stack.put_lds(p1 ? sp : stack.STACK_LDS, make_uint2((uint32_t)c[1], __float_as_uint(t[1])));
+        stack.put_lds(p2 ? sp + n01 - 1 : stack.STACK_LDS, make_uint2((uint32_t)c[2], __float_as_uint(t[2])));
+        stack.put_lds(p3 ? sp + n012 - 1 : stack.STACK_LDS, make_uint2((uint32_t)c[3], __float_as_uint(t[3])));
+      } else {
+        if (p1) stack.put(sp, make_uint2((uint32_t)c[1], __float_as_uint(t[1])));
+        if (p2) stack.put(sp + n01 - 1, make_uint2((uint32_t)c[2], __float_as_uint(t[2])));
+        if (p3) stack.put(sp + n012 - 1, make_uint2((uint32_t)c[3], __float_as_uint(t[3])));
+      }
+      sp += nacc - 1;
+      cur = a0 ? c[0] : (a1 ? c[1] : (a2 ? c[2] : c[3]));
+      cur_t = a0 ? t[0] : (a1 ? t[1] : (a2 ? t[2] : t[3]));
+      return;
     }
     cswap(t[0], c[0], t[1], c[1]);
     cswap(t[2], c[2], t[3], c[3]);
@@ -626,9 +654,11 @@ struct Walk {
   __device__ __forceinline__ bool trip(const DevScene &S, const TravStack &stack, uint32_t &n_nodes, uint32_t &n_tests,
                                        uint32_t &n_exact, float m0, double min_t, float min_lo, float min_hi,
                                        const End &ray_end, const Dmin &self_dmin, bool first_hit = false) {
+    // (wave-uniform: every lane that is here traces a first-hit ray)
+    const bool in_order = PTAMD_IN_ORDER && (ANY == 1 || (ANY == 2 && __ballot(!first_hit) == 0ull));
 #pragma unroll
     for (int k = 0; k < PTAMD_NODE_STEPS; k++)
-      if (cur >= 0) node_step<COUNT>(S, stack, n_nodes, m0);
+      if (cur >= 0) node_step<COUNT>(S, stack, n_nodes, m0, in_order);
     if (cur == CHILD_EMPTY) return true;
     if (cur < 0) return prim_step<ANY, COUNT>(S, stack, n_tests, n_exact, min_t, min_lo, min_hi, ray_end, self_dmin, first_hit);
     return false;
@@ -1157,7 +1187,9 @@ struct ShadowPolicy {
 
 template <bool HEMI, bool COUNT>
 __global__ void TRAV_BOUNDS_N(PTAMD_WAVES_SHADOW)
-    k_shadow(DevScene S, ShadowQ sq, VertexBuf vb, Ctl *ctl, FastDiv by_nls, uint2 *gstack) {
+    k_shadow(DevScene S, ShadowQ sq, VertexBuf vb, Ctl *ctl, FastDiv by_nls, uint2 *gstack, uint32_t fuse_below) {
+  // (the launch before, k_trace2, has traced these rays itself if the two lists were short: same test)
+  if (ctl->n_next + ctl->n_shadow < fuse_below) return;
   extern __shared__ uint2 lds_stack[];
   const TravStack stack{(lds_uint2 *)lds_stack, gstack, gridDim.x * blockDim.x, blockIdx.x * blockDim.x + threadIdx.x, PTAMD_STACK_SHADOW};
   uint32_t cn = 0, ct = 0, cx = 0;
@@ -1176,14 +1208,18 @@ __global__ void TRAV_BOUNDS_N(PTAMD_WAVES_SHADOW)
 template <bool HEMI, bool COUNT>
 __global__ void TRAV_BOUNDS_N(PTAMD_WAVES_EXTEND)
     k_trace2(DevScene S, RayQ q, const int32_t *__restrict__ list, HitBuf hb, ShadowQ sq, VertexBuf vb, Ctl *ctl,
-             FastDiv by_nls, uint2 *gstack) {
+             FastDiv by_nls, uint2 *gstack, uint32_t fuse_below) {
   extern __shared__ uint2 lds_stack[];
   const TravStack stack{(lds_uint2 *)lds_stack, gstack, gridDim.x * blockDim.x, blockIdx.x * blockDim.x + threadIdx.x, PTAMD_STACK_EXTEND};
   uint32_t cn = 0, ct = 0, cx = 0;
   const ExtendPolicy pe{q, list, hb, PT_EPS_D, (double)INFINITY, vb.self_code, vb.self_dmin};
   for (int k = 0; k < 3; k++) vb.hp[k] = q.o[k];  // the same arrays (see ptamd_trace_list): one set of pointers to hold
   const ShadowPolicy<HEMI> ps{S, sq, vb, by_nls};
-  const uint32_t n_e = ctl->n_next, n_s = ctl->n_shadow;
+  // Short lists are traced together (one drain phase instead of two, see trace_two_lists). Long
+  // shadow-ray lists are left to k_shadow, the next launch: first-hit walks carry less state and
+  // run at 7 waves per SIMD there instead of 5 here, which is worth more than the drain phase.
+  const uint32_t n_e = ctl->n_next;
+  const uint32_t n_s = (n_e + ctl->n_shadow < fuse_below) ? ctl->n_shadow : 0u;
   if (blockIdx.x == 0 && threadIdx.x == 0) {  // the only writer of these two during the launch
     ctl->st_two_ext += n_e;
     ctl->st_two_shadow += n_s;
@@ -1883,6 +1919,7 @@ struct ptamd_context {
   bool clear_ctl = false;  // the next ptamd_trace_list zeroes the device-side counters first
   double plan_margin = 1.5;  // RoundPlan::margin (PTAMD_PLAN_MARGIN in the environment: experiments)
   bool trace_two = true;  // bounce rays of depth d + 1 and shadow rays of depth d in one launch (PTAMD_TRACE_TWO=0: apart)
+  uint32_t fuse_below = 6u << 20;  // ... when the two lists together are shorter than this (PTAMD_FUSE_BELOW)
   int64_t max_paths = 16 << 20;  // paths per launch: large launches amortise the drain of the slowest waves
   int64_t cap_paths = 0;
   int cap_nls = 0;
@@ -2099,6 +2136,7 @@ int ptamd_create(int32_t device_id, ptamd_context **out) {
   if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) c->num_cu = prop.multiProcessorCount;
   if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) c->own_stream = nullptr;
   if (const char *e = getenv("PTAMD_TRACE_TWO")) c->trace_two = atoi(e) != 0;
+  if (const char *e = getenv("PTAMD_FUSE_BELOW")) c->fuse_below = (uint32_t)strtoul(e, nullptr, 10);
   if (const char *e = getenv("PTAMD_PLAN_MARGIN")) { const double m = atof(e); if (m >= 1.0 && m <= 8.0) c->plan_margin = m; }
   // The counters live apart from the work buffers: those are reallocated when a later round needs
   // more room, and a frame's statistics must survive that.
@@ -2612,25 +2650,28 @@ int ptamd_trace_list(ptamd_context *c, const ptamd_pixel_list *list, int32_t sam
       hipLaunchKernelGGL(k_scatter, ggrid, 256, 0, s, c->cp, vb, c->list[cur ^ 1], c->sq, c->ctl, fp.max_ray_depth > 0 ? fp.nls : 0);
       L.end();
       if (fp.max_ray_depth > 0 && fp.nls > 0) {
+        uint32_t shadow_skip = 0;  // k_shadow skips lists that k_trace2 has traced: those shorter than this
         if (depth < depths && c->trace_two) {
           // the next depth's bounce rays (queue cur ^ 1, just written) together with this depth's shadow rays;
           // the hit records of this depth have been consumed by k_shade
           L.begin(PTAMD_K_TRACE2);
           const bool hemi = fp.hemisphere != 0, cnt = c->prof_counters;
-#define PTAMD_LAUNCH_TRACE2(H, C) hipLaunchKernelGGL((k_trace2<H, C>), egrid, tblock, elds, s, c->S, c->q[cur ^ 1], (const int32_t *)c->list[cur ^ 1], c->hb, c->sq, vb, c->ctl, by_nls, gstack)
+#define PTAMD_LAUNCH_TRACE2(H, C) hipLaunchKernelGGL((k_trace2<H, C>), egrid, tblock, elds, s, c->S, c->q[cur ^ 1], (const int32_t *)c->list[cur ^ 1], c->hb, c->sq, vb, c->ctl, by_nls, gstack, c->fuse_below)
           if (hemi) { if (cnt) PTAMD_LAUNCH_TRACE2(true, true); else PTAMD_LAUNCH_TRACE2(true, false); }
           else { if (cnt) PTAMD_LAUNCH_TRACE2(false, true); else PTAMD_LAUNCH_TRACE2(false, false); }
 #undef PTAMD_LAUNCH_TRACE2
           L.end();
           traced_ahead = true;
-        } else {
+          shadow_skip = c->fuse_below;
+        }
+        if (shadow_skip != 0xffffffffu) {  // (all lists fused: not even the empty launch)
           L.begin(PTAMD_K_SHADOW);
           if (fp.hemisphere) {
-            if (c->prof_counters) hipLaunchKernelGGL((k_shadow<true, true>), sgrid, tblock, slds, s, c->S, c->sq, vb, c->ctl, by_nls, gstack);
-            else hipLaunchKernelGGL((k_shadow<true, false>), sgrid, tblock, slds, s, c->S, c->sq, vb, c->ctl, by_nls, gstack);
+            if (c->prof_counters) hipLaunchKernelGGL((k_shadow<true, true>), sgrid, tblock, slds, s, c->S, c->sq, vb, c->ctl, by_nls, gstack, shadow_skip);
+            else hipLaunchKernelGGL((k_shadow<true, false>), sgrid, tblock, slds, s, c->S, c->sq, vb, c->ctl, by_nls, gstack, shadow_skip);
           } else {
-            if (c->prof_counters) hipLaunchKernelGGL((k_shadow<false, true>), sgrid, tblock, slds, s, c->S, c->sq, vb, c->ctl, by_nls, gstack);
-            else hipLaunchKernelGGL((k_shadow<false, false>), sgrid, tblock, slds, s, c->S, c->sq, vb, c->ctl, by_nls, gstack);
+            if (c->prof_counters) hipLaunchKernelGGL((k_shadow<false, true>), sgrid, tblock, slds, s, c->S, c->sq, vb, c->ctl, by_nls, gstack, shadow_skip);
+            else hipLaunchKernelGGL((k_shadow<false, false>), sgrid, tblock, slds, s, c->S, c->sq, vb, c->ctl, by_nls, gstack, shadow_skip);
           }
           L.end();
         }

@@ -5,8 +5,8 @@ set -e
 mkdir -p gpurun_out/ab
 for v in "$@"; do
   if [ "$v" = base ]; then unset PTAMD_LIB; else export PTAMD_LIB=$PWD/pathtracer_amd/_variants/libptamd_$v.so; fi
-  timeout -k 10 200 python3 bench.py --scene bunny --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/ab/${v}_bunny.json 2> gpurun_out/ab/${v}_bunny.err
-  timeout -k 10 300 python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/ab/${v}_dragon.json 2> gpurun_out/ab/${v}_dragon.err
+  timeout -k 10 200 python3 bench.py $AB_ARGS --scene bunny --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/ab/${v}_bunny.json 2> gpurun_out/ab/${v}_bunny.err
+  timeout -k 10 300 python3 bench.py $AB_ARGS --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/ab/${v}_dragon.json 2> gpurun_out/ab/${v}_dragon.err
   echo "== $v"
   python3 tools/bench_brief.py gpurun_out/ab/${v}_bunny.json | sed -n 1,2p
   python3 tools/bench_brief.py gpurun_out/ab/${v}_dragon.json | sed -n 1,2p

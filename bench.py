@@ -393,9 +393,12 @@ def main():
                 "lane_ops_per_launch": pc["lane_ops_per_launch"],
                 "lane_ops_per_ray": pc["lane_ops_per_launch"] / max(roof.get("rays_per_launch") or 1, 1),
                 "valu_insts_per_ray": 64.0 * pc["valu_insts_per_launch"] / max(roof.get("rays_per_launch") or 1, 1),
-                # of the cycles of all SIMDs during the profiled launch, the share that issued a VALU
-                # instruction, and of the 64 lanes of those instructions the share that was active
-                "simd_cycles_issuing_valu": pc["valu_issue_cycles_per_launch"] / (pc["gpu_cycles_per_launch"] * N_SIMD),
+                # SQ_ACTIVE_INST_VALU x 4 over the cycles of all SIMDs during the profiled launch (a wave64
+                # instruction with every lane on occupies its SIMD for 4 cycles; the traversal kernels measure
+                # above 1 here with under half of their lanes on, so partly masked instructions cost less and
+                # this ratio is a diagnostic, not a bounded fraction - the lane-operation rate above is), and
+                # of the 64 lanes of those instructions the share that was active
+                "valu_insts_x4_per_simd_cycle": pc["valu_issue_cycles_per_launch"] / (pc["gpu_cycles_per_launch"] * N_SIMD),
                 "lanes_active": pc["lane_ops_per_launch"] / (64.0 * pc["valu_insts_per_launch"]),
                 "profiled_avg_launch_ms": pc["trace_avg_launch_ms"], "source": pc["source"]}
             roof["l2_measured"] = {"read_requests_per_launch": pc["l2_read_requests_per_launch"], "hit_rate": pc["l2_hit"],

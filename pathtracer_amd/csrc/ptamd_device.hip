@@ -100,7 +100,24 @@ struct DevScene {
   const double *jitter;
   int32_t n_lights, jitter_n, root_code, stack_cap;
   float coord_bound;  // no ray starts farther from the origin than this on any axis (prim32.h: big)
+#ifdef PTAMD_WAVELOG
+  // measurement build: every traversal wave writes when it started and ended (100 MHz ticks) at
+  // wavelog[2 * (wavelog_base + wave)]; the host names a fresh range per launch (tools/wave_drain.py)
+  unsigned long long *wavelog;
+  uint32_t wavelog_base, wavelog_cap;
+#endif
 };
+#ifdef PTAMD_WAVELOG
+#define PTAMD_WAVELOG_BEGIN const unsigned long long wl_t0 = wall_clock64();
+#define PTAMD_WAVELOG_END(S)                                                                                   \
+  if ((threadIdx.x & 63) == 0) {                                                                              \
+    const uint32_t wl_w = (S).wavelog_base + blockIdx.x * (blockDim.x / 64u) + (threadIdx.x >> 6);           \
+    if (wl_w < (S).wavelog_cap) { (S).wavelog[2 * (size_t)wl_w] = wl_t0; (S).wavelog[2 * (size_t)wl_w + 1] = wall_clock64(); } \
+  }
+#else
+#define PTAMD_WAVELOG_BEGIN
+#define PTAMD_WAVELOG_END(S)
+#endif
 
 struct FrameParams {
   int32_t w, h, max_ray_depth, accum, ns_area_light, hemisphere, nls, bpv, specular, pad;
@@ -1131,7 +1148,9 @@ __global__ void TRAV_BOUNDS_N(PTAMD_WAVES_EXTEND)
   const TravStack stack{(lds_uint2 *)lds_stack, gstack, gridDim.x * blockDim.x, blockIdx.x * blockDim.x + threadIdx.x, PTAMD_STACK_EXTEND};
   uint32_t cn = 0, ct = 0, cx = 0;
   const ExtendPolicy pol{q, list, hb, min_t, max_t, self_code, self_dmin};
+  PTAMD_WAVELOG_BEGIN
   trace_rays<0, COUNT, PTAMD_REFILL_EXTEND>(S, pol, ctl->n_cur, &ctl->grab[0], stack, cn, ct, cx);
+  PTAMD_WAVELOG_END(S)
   if (COUNT) {
     atomicAdd(&ctl->st_nodes, (unsigned long long)cn);
     atomicAdd(&ctl->st_tests, (unsigned long long)ct);
@@ -1194,8 +1213,10 @@ __global__ void TRAV_BOUNDS_N(PTAMD_WAVES_SHADOW)
   const TravStack stack{(lds_uint2 *)lds_stack, gstack, gridDim.x * blockDim.x, blockIdx.x * blockDim.x + threadIdx.x, PTAMD_STACK_SHADOW};
   uint32_t cn = 0, ct = 0, cx = 0;
   const ShadowPolicy<HEMI> pol{S, sq, vb, by_nls};
+  PTAMD_WAVELOG_BEGIN
   if (HEMI) trace_rays<0, COUNT, PTAMD_REFILL_SHADOW>(S, pol, ctl->n_shadow, &ctl->grab[1], stack, cn, ct, cx);
   else trace_rays<1, COUNT, PTAMD_REFILL_SHADOW>(S, pol, ctl->n_shadow, &ctl->grab[1], stack, cn, ct, cx);
+  PTAMD_WAVELOG_END(S)
   if (COUNT) {
     atomicAdd(&ctl->st_nodes, (unsigned long long)cn);
     atomicAdd(&ctl->st_tests, (unsigned long long)ct);
@@ -1224,7 +1245,9 @@ __global__ void TRAV_BOUNDS_N(PTAMD_WAVES_EXTEND)
     ctl->st_two_ext += n_e;
     ctl->st_two_shadow += n_s;
   }
+  PTAMD_WAVELOG_BEGIN
   trace_two_lists<HEMI, COUNT, PTAMD_REFILL_EXTEND>(S, pe, n_e, &ctl->grab[2], ps, n_s, &ctl->grab[1], stack, cn, ct, cx);
+  PTAMD_WAVELOG_END(S)
   if (COUNT) {
     atomicAdd(&ctl->st_nodes, (unsigned long long)cn);
     atomicAdd(&ctl->st_tests, (unsigned long long)ct);
@@ -2004,6 +2027,44 @@ struct Launcher {
   }
 };
 
+#ifdef PTAMD_WAVELOG
+struct WaveLogEntry { int kind; uint32_t base, waves; };
+static std::vector<WaveLogEntry> g_wavelog_launches;
+static uint32_t g_wavelog_used = 0;
+// names the range of the launch about to be queued (kind: 0 k_extend, 1 k_trace2, 2 k_shadow)
+static void wavelog_next(ptamd_context *c, int kind, int grid) {
+  const uint32_t waves = (uint32_t)grid * (TRAV_BLOCK / 64u);
+  if (!c->S.wavelog) {
+    c->S.wavelog_cap = 24u << 20;
+    if (hipMalloc((void **)&c->S.wavelog, (size_t)c->S.wavelog_cap * 16) != hipSuccess) { c->S.wavelog = nullptr; c->S.wavelog_cap = 0; }
+    else (void)hipMemset(c->S.wavelog, 0, (size_t)c->S.wavelog_cap * 16);
+  }
+  c->S.wavelog_base = g_wavelog_used;
+  if (g_wavelog_used + waves <= c->S.wavelog_cap) {
+    g_wavelog_launches.push_back({kind, g_wavelog_used, waves});
+    g_wavelog_used += waves;
+  } else {
+    c->S.wavelog_base = c->S.wavelog_cap;  // full: nothing more is written
+  }
+}
+// at ptamd_destroy: "kind base waves" per launch, then start / end ticks per wave, to $PTAMD_WAVELOG
+static void wavelog_dump(ptamd_context *c) {
+  const char *path = getenv("PTAMD_WAVELOG");
+  if (!path || !c->S.wavelog) return;
+  std::vector<unsigned long long> h((size_t)g_wavelog_used * 2);
+  if (hipMemcpy(h.data(), c->S.wavelog, h.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return;
+  FILE *f = fopen(path, "wb");
+  if (!f) return;
+  const uint32_t n = (uint32_t)g_wavelog_launches.size();
+  fwrite(&n, 4, 1, f);
+  for (const auto &e : g_wavelog_launches) { const uint32_t r[3] = {(uint32_t)e.kind, e.base, e.waves}; fwrite(r, 4, 3, f); }
+  fwrite(h.data(), 8, h.size(), f);
+  fclose(f);
+}
+#define PTAMD_WAVELOG_NEXT(c, kind, grid) wavelog_next(c, kind, grid)
+#else
+#define PTAMD_WAVELOG_NEXT(c, kind, grid)
+#endif
 void collect_events(ptamd_context *c) {
   for (auto &e : c->events) {
     float ms = 0;
@@ -2167,6 +2228,10 @@ void ptamd_destroy(ptamd_context *c) {
   (void)hipDeviceSynchronize();
   collect_events(c);
   for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
+#ifdef PTAMD_WAVELOG
+  wavelog_dump(c);
+  if (c->S.wavelog) (void)hipFree(c->S.wavelog);
+#endif
   free_scene(c);
   free_frame_scratch(c);
   if (c->slab) (void)hipFree(c->slab);
@@ -2630,6 +2695,7 @@ int ptamd_trace_list(ptamd_context *c, const ptamd_pixel_list *list, int32_t sam
       const int32_t *lst = depth == 1 ? nullptr : c->list[cur];
       if (!traced_ahead) {
         L.begin(PTAMD_K_EXTEND);
+        PTAMD_WAVELOG_NEXT(c, 0, egrid);
         if (c->prof_counters) hipLaunchKernelGGL((k_extend<true>), egrid, tblock, elds, s, c->S, c->q[cur], lst, c->hb, c->ctl, min_t, max_t, gstack, (const int32_t *)c->vb.self_code, (const float *)c->vb.self_dmin);
         else hipLaunchKernelGGL((k_extend<false>), egrid, tblock, elds, s, c->S, c->q[cur], lst, c->hb, c->ctl, min_t, max_t, gstack, (const int32_t *)c->vb.self_code, (const float *)c->vb.self_dmin);
         L.end();
@@ -2655,6 +2721,7 @@ int ptamd_trace_list(ptamd_context *c, const ptamd_pixel_list *list, int32_t sam
           // the next depth's bounce rays (queue cur ^ 1, just written) together with this depth's shadow rays;
           // the hit records of this depth have been consumed by k_shade
           L.begin(PTAMD_K_TRACE2);
+          PTAMD_WAVELOG_NEXT(c, 1, egrid);
           const bool hemi = fp.hemisphere != 0, cnt = c->prof_counters;
 #define PTAMD_LAUNCH_TRACE2(H, C) hipLaunchKernelGGL((k_trace2<H, C>), egrid, tblock, elds, s, c->S, c->q[cur ^ 1], (const int32_t *)c->list[cur ^ 1], c->hb, c->sq, vb, c->ctl, by_nls, gstack, c->fuse_below)
           if (hemi) { if (cnt) PTAMD_LAUNCH_TRACE2(true, true); else PTAMD_LAUNCH_TRACE2(true, false); }
@@ -2666,6 +2733,7 @@ int ptamd_trace_list(ptamd_context *c, const ptamd_pixel_list *list, int32_t sam
         }
         if (shadow_skip != 0xffffffffu) {  // (all lists fused: not even the empty launch)
           L.begin(PTAMD_K_SHADOW);
+          PTAMD_WAVELOG_NEXT(c, 2, sgrid);
           if (fp.hemisphere) {
             if (c->prof_counters) hipLaunchKernelGGL((k_shadow<true, true>), sgrid, tblock, slds, s, c->S, c->sq, vb, c->ctl, by_nls, gstack, shadow_skip);
             else hipLaunchKernelGGL((k_shadow<true, false>), sgrid, tblock, slds, s, c->S, c->sq, vb, c->ctl, by_nls, gstack, shadow_skip);

@@ -76,6 +76,12 @@ struct alignas(64) DevNode {
 };
 static_assert(sizeof(DevNode) == 64, "node must be half a cache line");
 constexpr int32_t CHILD_EMPTY = INT32_MIN;
+// A primitive's child code is ~(primitive | tag << 24): primitives number below 2^24 (checked at upload),
+// tag != 0 marks an end primitive of light tag - 1 (DevScene::light_end). A ray carries a word of the
+// same shape (Walk::skip): the primitive it starts on, or PRIM_NONE, and the tag of the light it is a
+// shadow ray to, or 0.
+constexpr uint32_t PRIM_BITS = 24, PRIM_NONE = (1u << PRIM_BITS) - 1u;
+constexpr uint32_t MAX_LIGHT_TAG = 7;
 
 // FP64 primitive record, 80 bytes (5 loads), read by exact_test. Triangle: p1,
 // e1 = p2-p1, e2 = p3-p1 rounded exactly as Triangle::test computes them on the fly
@@ -97,6 +103,12 @@ struct DevScene {
   const double *mat_extra;  // [n_materials*4] glass reflectance, ior (specular mode)
   const int32_t *light_kind;
   const double *light_param;
+  // Primitives that lie where a light's shadow rays END (the emissive quad an area light sits on), see
+  // find_light_end_prims: light_end[4 * li + k] = primitive or -1; light_tag[li] = the tag (1..7) their
+  // child codes carry, 0 if the light has none; has_end = any light has some.
+  const int32_t *light_end;
+  const int32_t *light_tag;
+  int32_t has_end;
   const double *jitter;
   int32_t n_lights, jitter_n, root_code, stack_cap;
   float coord_bound;  // no ray starts farther from the origin than this on any axis (prim32.h: big)
@@ -443,15 +455,15 @@ struct Walk {
   int sp;
   int32_t cur;
   float cur_t;        // where the ray enters cur's box (the box test's conservative near distance)
-  int32_t self_code;  // the primitive the ray starts on, when it may be skipped (VertexBuf::self_code)
+  uint32_t skip;  // primitive the ray starts on (VertexBuf::self_code) | tag of the light it ends on << 24
   // (a first-hit walk that has found a certain occluder says so with lo_f = NaN)
   __device__ __forceinline__ Hit result() const { return Hit{hit_prim, lo_f != lo_f}; }
 
   // (min_t is the same for every ray of a launch: the drivers hold it, and its float
   // neighbours, in scalar registers)
-  __device__ __forceinline__ void begin(const DevScene &S, v3 o_, v3 d_, double tmax, int32_t self) {
+  __device__ __forceinline__ void begin(const DevScene &S, v3 o_, v3 d_, double tmax, uint32_t skip_) {
     o = o_; d = d_;
-    self_code = self;
+    skip = skip_;
     rf = make_rayf(d);
     lo_f = f_down(tmax);
     best_f = f_up(tmax);
@@ -599,12 +611,18 @@ struct Walk {
   __device__ __forceinline__ bool prim_step(const DevScene &S, const TravStack &stack, uint32_t &n_tests, uint32_t &n_exact,
                                             double min_t, float min_lo, float min_hi, const End &ray_end,
                                             const Dmin &self_dmin, bool first_hit = false) {
-    const int p = (int)~(uint32_t)cur;
+    const uint32_t code = ~(uint32_t)cur;
+    const int p = (int)(code & PRIM_NONE);
+    // an end primitive of the light this shadow ray goes to: k_shade has tested it (and found no hit)
+    if ((code >> PRIM_BITS) != 0u && (code >> PRIM_BITS) == (skip >> PRIM_BITS)) {
+      pop(stack);
+      return cur == CHILD_EMPTY;
+    }
     if (COUNT) n_tests++;
     const uint4 *R = S.prim32 + (size_t)p * 3;
     const uint4 r0 = R[0], r1 = R[1], r2 = R[2];
     float dmin = INFINITY;
-    if (cur == self_code) dmin = self_dmin();
+    if ((uint32_t)p == (skip & PRIM_NONE)) dmin = self_dmin();
     const double p1x = __hiloint2double((int)r0.y, (int)r0.x), p1y = __hiloint2double((int)r0.w, (int)r0.z),
                  p1z = __hiloint2double((int)r1.y, (int)r1.x);
     // the origin moved to where the ray enters the primitive's box (prim32.h)
@@ -765,7 +783,7 @@ __device__ __forceinline__ void trace_rays(const DevScene &S, const Policy &pol,
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
       v3 o, d;
       double tmax;
-      int32_t self;
+      uint32_t self;
       if (!pol.load(i, o, d, tmax, self)) continue;
       w.begin(S, o, d, tmax, self);
       while (!w.template trip<ANY, COUNT>(S, stack, n_nodes, n_tests, n_exact, m0, min_t, min_lo, min_hi,
@@ -802,7 +820,7 @@ __device__ __forceinline__ void trace_rays(const DevScene &S, const Policy &pol,
           idx = mine;
           v3 o, d;
           double tmax;
-          int32_t self;
+          uint32_t self;
           if (pol.load(idx, o, d, tmax, self)) {
             w.begin(S, o, d, tmax, self);
             active = true;
@@ -884,7 +902,7 @@ __device__ __forceinline__ void trace_two_lists(const DevScene &S, const PolE &p
         idx = mine;
         v3 o, d;
         double tmax;
-        int32_t self;
+        uint32_t self;
         const bool have = phase == 0 ? pe.load(idx, o, d, tmax, self) : ps.load(idx, o, d, tmax, self);
         if (have) {
           w.begin(S, o, d, tmax, self);
@@ -1122,9 +1140,9 @@ struct ExtendPolicy {
   const float *dmin;
   __device__ __forceinline__ double min_t_all() const { return min_t; }
   // false: the slot holds no ray (see k_generate); its hit record says so
-  __device__ __forceinline__ bool load(uint32_t i, v3 &o, v3 &d, double &tmax, int32_t &self) const {
+  __device__ __forceinline__ bool load(uint32_t i, v3 &o, v3 &d, double &tmax, uint32_t &self) const {
     const uint32_t j = list ? (uint32_t)list[i] : i;
-    self = list ? self_code[j] : CHILD_EMPTY;  // camera rays start on nothing
+    self = list ? (uint32_t)self_code[j] : PRIM_NONE;  // camera rays start on nothing
     d = V(q.d[0][j], q.d[1][j], q.d[2][j]);
     if (!list && d.x == 0 && d.y == 0 && d.z == 0) {
       hb.prim[i] = PRIM_UNUSED;
@@ -1167,11 +1185,22 @@ struct ShadowPolicy {
   ShadowQ sq;
   VertexBuf vb;
   FastDiv by_nls;  // slot -> entry (exact for slot < 2^31, nls < 2^16: both enforced by ptamd_trace_list)
+  uint32_t nls, ns_area_light;
   __device__ __forceinline__ double min_t_all() const { return PT_EPS_D; }
-  __device__ __forceinline__ bool load(uint32_t i, v3 &o, v3 &d, double &tmax, int32_t &self) const {
+  // the tag of the light that sample q of a vertex goes to (k_shade's loop over the lights, backwards)
+  __device__ __forceinline__ uint32_t light_tag_of(uint32_t q) const {
+    for (int li = 0; li < S.n_lights; li++) {
+      const uint32_t ns = light_is_delta(S.light_kind[li]) ? 1u : ns_area_light;
+      if (q < ns) return (uint32_t)S.light_tag[li];
+      q -= ns;
+    }
+    return 0u;
+  }
+  __device__ __forceinline__ bool load(uint32_t i, v3 &o, v3 &d, double &tmax, uint32_t &self) const {
     const int32_t slot = sq.slot[i];
     const uint32_t e = by_nls.div((uint32_t)slot);
-    self = vb.self_code[e];
+    self = (uint32_t)vb.self_code[e];
+    if (!HEMI && S.has_end) self |= light_tag_of((uint32_t)slot - e * nls) << PRIM_BITS;
     o = V(vb.hp[0][e], vb.hp[1][e], vb.hp[2][e]);
     const SRay r = sq.ray[slot];
     d = V(r.d[0], r.d[1], r.d[2]);
@@ -1206,13 +1235,13 @@ struct ShadowPolicy {
 
 template <bool HEMI, bool COUNT>
 __global__ void TRAV_BOUNDS_N(PTAMD_WAVES_SHADOW)
-    k_shadow(DevScene S, ShadowQ sq, VertexBuf vb, Ctl *ctl, FastDiv by_nls, uint2 *gstack, uint32_t fuse_below) {
+    k_shadow(DevScene S, ShadowQ sq, VertexBuf vb, Ctl *ctl, FastDiv by_nls, uint2 nls_nsa, uint2 *gstack, uint32_t fuse_below) {
   // (the launch before, k_trace2, has traced these rays itself if the two lists were short: same test)
   if (ctl->n_next + ctl->n_shadow < fuse_below) return;
   extern __shared__ uint2 lds_stack[];
   const TravStack stack{(lds_uint2 *)lds_stack, gstack, gridDim.x * blockDim.x, blockIdx.x * blockDim.x + threadIdx.x, PTAMD_STACK_SHADOW};
   uint32_t cn = 0, ct = 0, cx = 0;
-  const ShadowPolicy<HEMI> pol{S, sq, vb, by_nls};
+  const ShadowPolicy<HEMI> pol{S, sq, vb, by_nls, nls_nsa.x, nls_nsa.y};
   PTAMD_WAVELOG_BEGIN
   if (HEMI) trace_rays<0, COUNT, PTAMD_REFILL_SHADOW>(S, pol, ctl->n_shadow, &ctl->grab[1], stack, cn, ct, cx);
   else trace_rays<1, COUNT, PTAMD_REFILL_SHADOW>(S, pol, ctl->n_shadow, &ctl->grab[1], stack, cn, ct, cx);
@@ -1229,13 +1258,13 @@ __global__ void TRAV_BOUNDS_N(PTAMD_WAVES_SHADOW)
 template <bool HEMI, bool COUNT>
 __global__ void TRAV_BOUNDS_N(PTAMD_WAVES_EXTEND)
     k_trace2(DevScene S, RayQ q, const int32_t *__restrict__ list, HitBuf hb, ShadowQ sq, VertexBuf vb, Ctl *ctl,
-             FastDiv by_nls, uint2 *gstack, uint32_t fuse_below) {
+             FastDiv by_nls, uint2 nls_nsa, uint2 *gstack, uint32_t fuse_below) {
   extern __shared__ uint2 lds_stack[];
   const TravStack stack{(lds_uint2 *)lds_stack, gstack, gridDim.x * blockDim.x, blockIdx.x * blockDim.x + threadIdx.x, PTAMD_STACK_EXTEND};
   uint32_t cn = 0, ct = 0, cx = 0;
   const ExtendPolicy pe{q, list, hb, PT_EPS_D, (double)INFINITY, vb.self_code, vb.self_dmin};
   for (int k = 0; k < 3; k++) vb.hp[k] = q.o[k];  // the same arrays (see ptamd_trace_list): one set of pointers to hold
-  const ShadowPolicy<HEMI> ps{S, sq, vb, by_nls};
+  const ShadowPolicy<HEMI> ps{S, sq, vb, by_nls, nls_nsa.x, nls_nsa.y};
   // Short lists are traced together (one drain phase instead of two, see trace_two_lists). Long
   // shadow-ray lists are left to k_shadow, the next launch: first-hit walks carry less state and
   // run at 7 waves per SIMD there instead of 5 here, which is worth more than the drain phase.
@@ -1465,7 +1494,7 @@ __global__ void __launch_bounds__(256)
           // grazes the triangle (|D| tiny). T is computed here as Triangle::test computes it
           // (src/scene/triangle.cpp:33-36), and the walks get the |D| above which |T / D| is
           // certainly below min_t (prim32.h, classify_tri32: dmin).
-          int32_t self = CHILD_EMPTY;
+          int32_t self = (int32_t)PRIM_NONE;
           float dmin = INFINITY;
           if (!(info & 1)) {
             const double *P = S.prim + (size_t)prim * PRIM_STRIDE;
@@ -1473,7 +1502,7 @@ __global__ void __launch_bounds__(256)
             const double Tn = vdot(vcross(sv, V(P[3], P[4], P[5])), V(P[6], P[7], P[8]));
             const float tu = fmaxf(f_up(fabs(Tn)), 7.888609052210118e-31f /* 2^-100 */);
             dmin = (tu * 1.002f) / f_down(PT_EPS_D);
-            self = ~prim;
+            self = prim;
           }
           vb.self_code[i] = self;
           vb.self_dmin[i] = dmin;
@@ -1504,7 +1533,20 @@ __global__ void __launch_bounds__(256)
             const v3 radiance = light_sample_L(S, li, hit_p, sx, sy, wi, dist, pdf);
             const v3 wi_o = mmul(w2o, wi);
             const size_t slot = (size_t)i * nls + qq;
-            if (!(wi_o.z < 0 || (radiance.x == 0 && radiance.y == 0 && radiance.z == 0))) {
+            bool emit = !(wi_o.z < 0 || (radiance.x == 0 && radiance.y == 0 && radiance.z == 0));
+            // The primitives at the far end of this light's shadow rays are tested here, by the reference's
+            // test and its rule (bvh.cpp:187: a hit strictly before the ray's end occludes), with every
+            // lane busy; a ray they occlude is never traced, and the walk of the others skips them.
+            if (emit && S.has_end && S.light_tag[li]) {
+#pragma unroll 1
+              for (int k = 0; k < 4; k++) {
+                const int32_t ep = S.light_end[4 * li + k];
+                if (ep < 0) break;
+                double te, ue, ve;
+                if (exact_test(S, ep, hit_p, wi, PT_EPS_D, te, ue, ve) && te < dist) { emit = false; break; }
+              }
+            }
+            if (emit) {
               const v3 term = vdivs(vscale(vmul(f, radiance), fabs(wi_o.z)), pdf);
               sq.ray[slot] = SRay{{wi.x, wi.y, wi.z}, dist};
               vb.contrib[slot] = Contrib{{term.x, term.y, term.z}};
@@ -2360,11 +2402,63 @@ int ptamd_upload_scene(ptamd_context *c, const ptamd_scene_desc *d) {
     if (d->prim_material[p] < 0 || d->prim_material[p] >= d->n_materials) { ptamd::set_error("primitive material index out of range"); return PTAMD_ERR_SCENE; }
     if (d->prim_type[p] != PTAMD_PRIM_TRIANGLE && d->prim_type[p] != PTAMD_PRIM_SPHERE) { ptamd::set_error("unknown primitive type"); return PTAMD_ERR_SCENE; }
   }
+  if (NP >= (int)PRIM_NONE) { ptamd::set_error("more than 2^24 - 2 primitives are not supported"); return PTAMD_ERR_SCENE; }
   // ---- collapse the binary tree into 4-wide nodes whose children are nodes or
   // single primitives. new_index[p] = position of the caller's primitive p in
   // visiting order (the device's primitive index).
   std::vector<int32_t> new_index(NP);
   for (int i = 0; i < NP; i++) new_index[visit_order[i]] = i;
+  // ---- The primitives at the far end of an area light's shadow rays. The CB scenes' light is a
+  // rectangle that coincides with an emissive quad of the geometry (to within the 5e-8 the
+  // quad's float coordinates are off), and the reference's shadow rays end ON the light
+  // (max_t = distToLight, pathtracer.cpp:125): whether the quad occludes such a ray is decided
+  // by the last bits of an FP64 test, which no float pre-test can settle, for every shadow ray
+  // of the frame. So up to four triangles that lie in a light's plane and overlap its rectangle
+  // are listed per light (the first seven area lights): k_shade runs the reference's test on them
+  // when it makes a shadow ray, and the ray's walk skips the primitives that carry its light's
+  // tag. Which primitives are listed only decides where they are tested, not the result: a
+  // shadow ray is occluded iff some primitive's test hits strictly before its end, in any order.
+  std::vector<int32_t> light_end(4 * (size_t)std::max(d->n_lights, 1), -1), light_tag(std::max(d->n_lights, 1), 0);
+  std::vector<uint8_t> prim_tag(NP, 0);
+  int has_end = 0;
+  {
+    uint32_t next_tag = 1;
+    for (int li = 0; li < d->n_lights && next_tag <= MAX_LIGHT_TAG; li++) {
+      if (d->light_kind[li] != PTAMD_LIGHT_AREA) continue;
+      const double *L = d->light_param + 16 * (size_t)li;
+      const double *c0 = L + 3, *nrm = L + 6, *dx = L + 9, *dy = L + 12;
+      double lo[3], hi[3], scale = 0;
+      for (int k = 0; k < 3; k++) {
+        const double ex = 0.5 * (std::fabs(dx[k]) + std::fabs(dy[k]));
+        lo[k] = c0[k] - ex; hi[k] = c0[k] + ex;
+        scale = std::max(scale, std::max(std::fabs(lo[k]), std::fabs(hi[k])));
+      }
+      const double eps = 1e-5 * (1.0 + scale);
+      int found = 0;
+      for (int i = 0; i < NP && found < 4; i++) {  // in the device's primitive order
+        const int p = visit_order[i];
+        if (d->prim_type[p] != PTAMD_PRIM_TRIANGLE || prim_tag[p]) continue;
+        const double *P = d->prim_pos + 9 * (size_t)p;
+        bool in_plane = true, overlaps = true;
+        for (int v = 0; v < 3 && in_plane; v++) {
+          const double h = (P[3 * v] - c0[0]) * nrm[0] + (P[3 * v + 1] - c0[1]) * nrm[1] + (P[3 * v + 2] - c0[2]) * nrm[2];
+          in_plane = std::fabs(h) <= eps;
+        }
+        if (!in_plane) continue;
+        for (int k = 0; k < 3; k++) {
+          const double tlo = std::min(P[k], std::min(P[3 + k], P[6 + k])), thi = std::max(P[k], std::max(P[3 + k], P[6 + k]));
+          if (thi < lo[k] - eps || tlo > hi[k] + eps) overlaps = false;
+        }
+        if (!overlaps) continue;
+        light_end[4 * (size_t)li + found++] = i;
+        prim_tag[p] = (uint8_t)next_tag;
+      }
+      if (found) {
+        light_tag[li] = (int32_t)next_tag++;
+        has_end = 1;
+      }
+    }
+  }
   struct Item { int32_t node; int32_t prim; };  // node >= 0: a node of the caller's tree; else the caller's primitive
   auto prim_box = [&](int p, double bb[6]) {
     const double *P = d->prim_pos + 9 * (size_t)p;
@@ -2453,7 +2547,7 @@ int ptamd_upload_scene(ptamd_context *c, const ptamd_scene_desc *d) {
     }
     for (size_t k = 0; k < kids.size(); k++) {
       if (kids[k].node < 0) {
-        nodes[f.node4].child[k] = ~new_index[kids[k].prim];
+        nodes[f.node4].child[k] = (int32_t)~((uint32_t)new_index[kids[k].prim] | ((uint32_t)prim_tag[kids[k].prim] << PRIM_BITS));
       } else {
         DevNode nn;
         memset(&nn, 0, sizeof nn);
@@ -2535,6 +2629,9 @@ int ptamd_upload_scene(ptamd_context *c, const ptamd_scene_desc *d) {
   if ((rc = upload(c, mp, &S.mat_param))) return rc;
   if ((rc = upload(c, me, &S.mat_extra))) return rc;
   if ((rc = upload(c, lk, &S.light_kind))) return rc;
+  if ((rc = upload(c, light_end, &S.light_end))) return rc;
+  if ((rc = upload(c, light_tag, &S.light_tag))) return rc;
+  S.has_end = has_end;
   if ((rc = upload(c, lp, &S.light_param))) return rc;
   if ((rc = upload(c, jt, &S.jitter))) return rc;
   S.n_lights = d->n_lights;
@@ -2651,6 +2748,7 @@ int ptamd_trace_list(ptamd_context *c, const ptamd_pixel_list *list, int32_t sam
     return PTAMD_ERR_ARG;
   }
   const FastDiv by_nls = make_fastdiv((uint32_t)nls);
+  const uint2 nls_nsa = make_uint2((uint32_t)nls, (uint32_t)std::max(fp.ns_area_light, 0));  // light samples per vertex, per area light
   // paths per launch: max_paths, but never more than a 24 GB slab of work buffers
   // (about 290 bytes per path + 70 per light-sample slot), and never so many that a light-sample
   // slot index (entry * nls + q, an int32) would pass 2^31
@@ -2723,7 +2821,7 @@ int ptamd_trace_list(ptamd_context *c, const ptamd_pixel_list *list, int32_t sam
           L.begin(PTAMD_K_TRACE2);
           PTAMD_WAVELOG_NEXT(c, 1, egrid);
           const bool hemi = fp.hemisphere != 0, cnt = c->prof_counters;
-#define PTAMD_LAUNCH_TRACE2(H, C) hipLaunchKernelGGL((k_trace2<H, C>), egrid, tblock, elds, s, c->S, c->q[cur ^ 1], (const int32_t *)c->list[cur ^ 1], c->hb, c->sq, vb, c->ctl, by_nls, gstack, c->fuse_below)
+#define PTAMD_LAUNCH_TRACE2(H, C) hipLaunchKernelGGL((k_trace2<H, C>), egrid, tblock, elds, s, c->S, c->q[cur ^ 1], (const int32_t *)c->list[cur ^ 1], c->hb, c->sq, vb, c->ctl, by_nls, nls_nsa, gstack, c->fuse_below)
           if (hemi) { if (cnt) PTAMD_LAUNCH_TRACE2(true, true); else PTAMD_LAUNCH_TRACE2(true, false); }
           else { if (cnt) PTAMD_LAUNCH_TRACE2(false, true); else PTAMD_LAUNCH_TRACE2(false, false); }
 #undef PTAMD_LAUNCH_TRACE2
@@ -2735,11 +2833,11 @@ int ptamd_trace_list(ptamd_context *c, const ptamd_pixel_list *list, int32_t sam
           L.begin(PTAMD_K_SHADOW);
           PTAMD_WAVELOG_NEXT(c, 2, sgrid);
           if (fp.hemisphere) {
-            if (c->prof_counters) hipLaunchKernelGGL((k_shadow<true, true>), sgrid, tblock, slds, s, c->S, c->sq, vb, c->ctl, by_nls, gstack, shadow_skip);
-            else hipLaunchKernelGGL((k_shadow<true, false>), sgrid, tblock, slds, s, c->S, c->sq, vb, c->ctl, by_nls, gstack, shadow_skip);
+            if (c->prof_counters) hipLaunchKernelGGL((k_shadow<true, true>), sgrid, tblock, slds, s, c->S, c->sq, vb, c->ctl, by_nls, nls_nsa, gstack, shadow_skip);
+            else hipLaunchKernelGGL((k_shadow<true, false>), sgrid, tblock, slds, s, c->S, c->sq, vb, c->ctl, by_nls, nls_nsa, gstack, shadow_skip);
           } else {
-            if (c->prof_counters) hipLaunchKernelGGL((k_shadow<false, true>), sgrid, tblock, slds, s, c->S, c->sq, vb, c->ctl, by_nls, gstack, shadow_skip);
-            else hipLaunchKernelGGL((k_shadow<false, false>), sgrid, tblock, slds, s, c->S, c->sq, vb, c->ctl, by_nls, gstack, shadow_skip);
+            if (c->prof_counters) hipLaunchKernelGGL((k_shadow<false, true>), sgrid, tblock, slds, s, c->S, c->sq, vb, c->ctl, by_nls, nls_nsa, gstack, shadow_skip);
+            else hipLaunchKernelGGL((k_shadow<false, false>), sgrid, tblock, slds, s, c->S, c->sq, vb, c->ctl, by_nls, nls_nsa, gstack, shadow_skip);
           }
           L.end();
         }

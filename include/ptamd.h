@@ -179,7 +179,9 @@ double ptamd_scene_build_seconds(const ptamd_scene *scene);
  * PathTracer::raytrace_pixel (src/pathtracer/pathtracer.cpp:234-272). */
 int ptamd_create(int32_t device_id, ptamd_context **out);
 void ptamd_destroy(ptamd_context *ctx);
-/* Copies the scene to the device (replaces set_scene + build_accel's hand-over). */
+/* Copies the scene to the device (replaces set_scene + build_accel's hand-over).
+ * Limits (PTAMD_ERR_SCENE otherwise): leaves of at most 4 primitives (the reference builds with
+ * max_leaf_size = 4), fewer than 2^24 - 1 primitives, coordinates below 2^20 in magnitude. */
 int ptamd_upload_scene(ptamd_context *ctx, const ptamd_scene_desc *desc);
 /* Replaces RaytracedRenderer::set_camera (raytraced_renderer.cpp:136-149). */
 int ptamd_set_camera(ptamd_context *ctx, const ptamd_camera *cam);

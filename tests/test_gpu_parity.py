@@ -135,6 +135,44 @@ def test_every_light_kind_matches_oracle(device, kind, param):
             assert hdr.max() > 0
 
 
+@pytest.mark.parametrize("variant", ["floating", "above_the_quad", "two_on_one_quad"])
+def test_area_lights_and_the_geometry_at_their_far_end(device, variant):
+    """The device tests the primitives an area light's shadow rays end on (the emissive quad the
+    CB scenes' light coincides with) where the ray is made, and lets the walk skip them. The
+    other ways a shadow ray can meet such geometry must give the reference's answer too:
+    a light with no geometry in its plane; a second light just above the quad, whose rays cross
+    the first light's quad before their end; two lights on the same quad, of which only one
+    can own its triangles."""
+    w, h = 64, 48
+    sc, arr, cam = _load("CBspheres_lambertian", w, h)
+    a = dict(arr.a)
+    base = np.array(arr.a["light_param"][:16], np.float64)
+    assert arr.a["light_kind"][0] == cabi.LIGHT_AREA
+    if variant == "floating":
+        rec = base.copy()
+        rec[4] -= 0.01
+        kinds, params = [cabi.LIGHT_AREA], rec
+    else:
+        second = base.copy()
+        second[9:15] *= 0.5
+        second[15] *= 0.25
+        if variant == "above_the_quad":
+            second[4] += 0.004
+        kinds, params = [cabi.LIGHT_AREA, cabi.LIGHT_AREA], np.concatenate([base, second])
+    a["light_kind"] = np.array(kinds, np.int32)
+    a["light_param"] = params
+    mod = cabi.SceneArrays(a, arr.root)
+    device.upload(mod)
+    device.set_camera(cam)
+    p = cabi.make_params(w, h, ns_aa=32, max_ray_depth=3, ns_area_light=2, seed=33)
+    hdr, cnt = device.render(p)
+    rh, rc, _ = O.render(mod, cam, p, threads=8)
+    assert (cnt == rc).mean() >= 0.999
+    close = np.isclose(hdr, rh, rtol=1e-9, atol=1e-12).all(axis=2)
+    assert close.mean() >= 0.999, "%s: %.3f%% of pixels differ beyond rounding" % (variant, 100 * (1 - close.mean()))
+    assert hdr.max() > 0
+
+
 @pytest.mark.parametrize("nls,with_point", [(3, False), (5, True)])
 def test_light_sample_slots_beyond_2_pow_23(device, nls, with_point):
     """One launch of 15.36 M path entries whose light-sample count per vertex is not a power of

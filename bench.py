@@ -181,7 +181,10 @@ def profiled_counters(scene, kernel):
                 "gpu_cycles_per_launch": grbm["GRBM_GUI_ACTIVE"] / 8.0 / grbm["_dispatches"],
                 "l2_read_requests_per_launch": l1["TCP_TCC_READ_REQ_sum"] / l1["_dispatches"],
                 "trace_avg_launch_ms": d["kernels"][k]["avg_us"] / 1e3,
-                "l2_hit": d["pmc_l2"][k]["TCC_HIT_sum"] / max(d["pmc_l2"][k]["TCC_HIT_sum"] + d["pmc_l2"][k]["TCC_MISS_sum"], 1)}
+                "l2_hit": d["pmc_l2"][k]["TCC_HIT_sum"] / max(d["pmc_l2"][k]["TCC_HIT_sum"] + d["pmc_l2"][k]["TCC_MISS_sum"], 1),
+                # rays per launch of the profiled run, when this kernel was the one it reported on
+                "rays_per_launch": (d.get("bench", {}).get("roofline", {}).get("rays_per_launch")
+                                    if d.get("bench", {}).get("roofline", {}).get("kernel") == kernel else None)}
     except Exception:
         return None
 
@@ -381,7 +384,19 @@ def main():
         # ---- the binding ceiling of a BVH walk: VALU instruction issue. Lane-operations per launch come
         # from the committed counter passes of this same command line, the time per launch is measured
         # live (HIP events on the launch stream).
-        pc = profiled_counters(args.scene, names[dom]) if standard and args.pixel_stride == 1 else None
+        pc = profiled_counters(args.scene, names[dom]) if standard else None
+        if pc and (world > 1 or args.pixel_stride > 1):
+            # the profile is of the whole frame on one GPU; a share of the frame has smaller launches. A
+            # traversal kernel's work is proportional to its rays, which are counted live on both sides
+            live, prof = roof.get("rays_per_launch"), pc.get("rays_per_launch")
+            if live and prof:
+                scale = live / prof
+                for k in ("lane_ops_per_launch", "valu_insts_per_launch", "valu_issue_cycles_per_launch",
+                          "gpu_cycles_per_launch", "l2_read_requests_per_launch"):
+                    pc[k] *= scale
+                pc["scaled_by_rays"] = scale
+            else:
+                pc = None
         if pc and ms > 0:
             t_launch = ms * 1e-3 / n_launch
             ach = pc["lane_ops_per_launch"] / t_launch / 1e12
@@ -401,10 +416,12 @@ def main():
                 "valu_insts_x4_per_simd_cycle": pc["valu_issue_cycles_per_launch"] / (pc["gpu_cycles_per_launch"] * N_SIMD),
                 "lanes_active": pc["lane_ops_per_launch"] / (64.0 * pc["valu_insts_per_launch"]),
                 "profiled_avg_launch_ms": pc["trace_avg_launch_ms"], "source": pc["source"]}
+            if "scaled_by_rays" in pc:
+                roof["issue"]["profile_scaled_by_rays_per_launch"] = pc["scaled_by_rays"]
             roof["l2_measured"] = {"read_requests_per_launch": pc["l2_read_requests_per_launch"], "hit_rate": pc["l2_hit"],
                                    "achieved_gbs_at_64B": pc["l2_read_requests_per_launch"] * 64 / t_launch / 1e9,
                                    "peak": L2_PEAK_GBS}
-        if standard:
+        if standard and world == 1 and args.pixel_stride == 1:
             tr, src = profiled_traffic(args.scene, names[dom])
             roof["traffic"], roof["traffic_source"] = tr, src
             if tr and ms > 0:

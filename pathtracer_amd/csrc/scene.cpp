@@ -245,60 +245,70 @@ Light make_light(const LightInfo &li, const M4 &T) {
 }  // namespace
 
 // --------------------------------------------------------------------------- camera
-void CameraState::configure(const CameraInfo &info, size_t sw, size_t sh) {  // camera.cpp:29-47
+// Camera set-up. The numbers below have to come out bit for bit as the reference's
+// (src/pathtracer/camera.cpp:29-146) computes them, so every expression keeps the reference's
+// operations and their order; the decomposition is this file's own.
+namespace {
+// tan of half a field of view given in degrees: tan(radians(fov) / 2)
+double half_tan(double fov_deg) { return tan(radians(fov_deg) / 2); }
+// the field of view (degrees) that spans `extent` pixels at `dist` pixels: 2 degrees(atan(extent / (2 dist)))
+double fov_spanning(size_t extent, double dist) { return 2 * degrees(atan(((double)extent) / (2 * dist))); }
+}  // namespace
+
+// camera.cpp:29-47: take the COLLADA camera's fields of view, widen whichever is too narrow for the
+// window's aspect ratio, and fix the distance of the image plane in pixels from the vertical one.
+void CameraState::configure(const CameraInfo &info, size_t sw, size_t sh) {
   screenW = sw;
   screenH = sh;
   nClip = info.nClip;
   fClip = info.fClip;
   hFov = info.hFov;
   vFov = info.vFov;
-  double ar1 = tan(radians(hFov) / 2) / tan(radians(vFov) / 2);
   ar = static_cast<double>(screenW) / screenH;
-  if (ar1 < ar) {
-    hFov = 2 * degrees(atan(tan(radians(vFov) / 2) * ar));
-  } else if (ar1 > ar) {
-    vFov = 2 * degrees(atan(tan(radians(hFov) / 2) / ar));
-  }
-  screenDist = ((double)screenH) / (2.0 * tan(radians(vFov) / 2));
+  const double described = half_tan(hFov) / half_tan(vFov);  // the aspect ratio the two angles describe
+  if (described < ar) hFov = 2 * degrees(atan(half_tan(vFov) * ar));
+  else if (described > ar) vFov = 2 * degrees(atan(half_tan(hFov) / ar));
+  screenDist = ((double)screenH) / (2.0 * half_tan(vFov));
 }
 
+// camera.cpp:53-65: spherical coordinates around a target; r is clamped, and an angle whose sine
+// vanishes is nudged off the pole before it is stored.
 void CameraState::place(const V3 &target, double phi_in, double theta_in, double r_in, double minR_in,
-                        double maxR_in) {  // camera.cpp:53-65
-  double r_ = std::min(std::max(r_in, minR_in), maxR_in);
-  double phi_ = (sin(phi_in) == 0) ? (phi_in + EPS_F) : phi_in;
+                        double maxR_in) {
   targetPos = target;
-  phi = phi_;
-  theta = theta_in;
-  r = r_;
   minR = minR_in;
   maxR = maxR_in;
+  r = std::min(std::max(r_in, minR_in), maxR_in);
+  phi = (sin(phi_in) == 0) ? (phi_in + EPS_F) : phi_in;
+  theta = theta_in;
   compute_position();
 }
 
-void CameraState::set_screen_size(size_t sw, size_t sh) {  // camera.cpp:83-89
+// camera.cpp:83-89: a new window keeps the image-plane distance, so both angles follow the size
+void CameraState::set_screen_size(size_t sw, size_t sh) {
   screenW = sw;
   screenH = sh;
   ar = 1.0 * screenW / screenH;
-  hFov = 2 * degrees(atan(((double)screenW) / (2 * screenDist)));
-  vFov = 2 * degrees(atan(((double)screenH) / (2 * screenDist)));
+  hFov = fov_spanning(screenW, screenDist);
+  vFov = fov_spanning(screenH, screenDist);
 }
 
-void CameraState::compute_position() {  // camera.cpp:123-146
-  double sinPhi = sin(phi);
-  if (sinPhi == 0) {
+// camera.cpp:123-146: position and camera-to-world frame from (phi, theta, r). Columns of c2w:
+// screen x = up x back, screen y = back x screen x, and the unit vector from the target to the camera.
+void CameraState::compute_position() {
+  double s_phi = sin(phi);
+  if (s_phi == 0) {
     phi += EPS_F;
-    sinPhi = sin(phi);
+    s_phi = sin(phi);
   }
-  const V3 dirToCamera(r * sinPhi * sin(theta), r * cos(phi), r * sinPhi * cos(theta));
-  pos = targetPos + dirToCamera;
-  V3 upVec(0, sinPhi > 0 ? 1 : -1, 0);
-  V3 screenXDir = cross(upVec, dirToCamera);
-  normalize(screenXDir);
-  V3 screenYDir = cross(dirToCamera, screenXDir);
-  normalize(screenYDir);
-  c2w.col[0] = screenXDir;
-  c2w.col[1] = screenYDir;
-  c2w.col[2] = unit(dirToCamera);
+  const V3 back(r * s_phi * sin(theta), r * cos(phi), r * s_phi * cos(theta));
+  pos = targetPos + back;
+  const V3 up(0, s_phi > 0 ? 1 : -1, 0);
+  c2w.col[0] = cross(up, back);
+  normalize(c2w.col[0]);
+  c2w.col[1] = cross(back, c2w.col[0]);
+  normalize(c2w.col[1]);
+  c2w.col[2] = unit(back);
 }
 
 // The camera settings file (written by Camera::dump_settings, read by Camera::load_settings,

@@ -16,6 +16,8 @@
 
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -23,7 +25,34 @@
 #include "../../include/ptamd.h"
 #include "error_state.h"
 
+// Where the host threads of a frame meet before the exchange: a GPU whose part failed must not
+// leave the others waiting in a send or receive that will never be matched.
+struct Rendezvous {
+  std::mutex mu;
+  std::condition_variable cv;
+  int waiting = 0;
+  unsigned generation = 0;
+  bool failed = false, result = false;
+  // blocks until all n threads have arrived; true if any of them reported a failure
+  bool arrive(bool i_failed, int n) {
+    std::unique_lock<std::mutex> lk(mu);
+    failed = failed || i_failed;
+    if (++waiting == n) {
+      result = failed;
+      failed = false;
+      waiting = 0;
+      generation++;
+      cv.notify_all();
+      return result;
+    }
+    const unsigned g = generation;
+    cv.wait(lk, [&] { return generation != g; });
+    return result;
+  }
+};
+
 struct ptamd_multi {
+  Rendezvous meet;
   std::vector<int32_t> devices;
   std::vector<ptamd_context *> ctx;
   std::vector<ncclComm_t> comm;
@@ -73,9 +102,9 @@ int grow(T **p, int64_t *cap, int64_t need, std::string &err) {
   return PTAMD_OK;
 }
 
-// what GPU `r` does for one frame; errors come back as text (ptamd_last_error is per thread)
-int render_rank(ptamd_multi *m, int r, const ptamd_render_params *p, const std::vector<int32_t> &all,
-                double *hdr_out, int32_t *count_out, std::string &err) {
+// GPU `r`'s own part of a frame: its pixels traced, its rows packed (all queued on its stream);
+// errors come back as text (ptamd_last_error is per thread)
+int trace_rank(ptamd_multi *m, int r, const ptamd_render_params *p, const std::vector<int32_t> &all, std::string &err) {
   const int n = (int)m->ctx.size();
   ptamd_multi::PerGpu &g = m->gpu[r];
   hipStream_t s = m->stream[r];
@@ -93,12 +122,24 @@ int render_rank(ptamd_multi *m, int r, const ptamd_render_params *p, const std::
   M_HIP(hipMemsetAsync(g.d_state, 0, (size_t)npix * 6 * sizeof(double), s));
   M_HIP(hipStreamSynchronize(s));  // `mine` is about to go out of use on the host side of the copy
   M_PT(ptamd_render_list(m->ctx[r], p, g.d_mine, n_mine, g.d_state, s));
-  const ptamd_pixel_list whole{g.d_all, nullptr, n_all, n_all, 0, 1};
-  if (n > 1 && n_all > 0) {
-    // the one exchange of the frame: every GPU's finished rows to GPU 0
+  if (n > 1 && n_all > 0 && r > 0) {
     const ptamd_pixel_list shard{g.d_all, nullptr, n_all, n_all, r, n};
     M_HIP(hipMemsetAsync(g.d_send, 0, (size_t)rows * 6 * sizeof(double), s));
     M_PT(ptamd_pack_rows(m->ctx[r], &shard, g.d_state, g.d_send, s));
+  }
+  return PTAMD_OK;
+}
+
+// the one exchange of the frame (every GPU's finished rows to GPU 0) and, on GPU 0, the frame
+int gather_rank(ptamd_multi *m, int r, const ptamd_render_params *p, const std::vector<int32_t> &all,
+                double *hdr_out, int32_t *count_out, std::string &err) {
+  const int n = (int)m->ctx.size();
+  ptamd_multi::PerGpu &g = m->gpu[r];
+  hipStream_t s = m->stream[r];
+  const int64_t npix = (int64_t)p->w * p->h, n_all = (int64_t)all.size();
+  const int64_t rows = ptamd_multi_rows_per_rank(n_all, n);
+  const ptamd_pixel_list whole{g.d_all, nullptr, n_all, n_all, 0, 1};
+  if (n > 1 && n_all > 0) {
     M_NCCL(ncclGroupStart());
     if (r == 0) {
       for (int peer = 1; peer < n; peer++)
@@ -243,7 +284,16 @@ int ptamd_multi_render(ptamd_multi *m, const ptamd_render_params *p, double *hdr
     if (rc) { ptamd::set_error(err); return rc; }
   }
   const auto t0 = std::chrono::steady_clock::now();
-  const int rc = on_every_gpu(m, [&](int r, std::string &err) { return render_rank(m, r, p, all, hdr_out, count_out, err); });
+  const int rc = on_every_gpu(m, [&](int r, std::string &err) {
+    const int rc_trace = trace_rank(m, r, p, all, err);
+    // nobody enters the exchange unless everybody can
+    if (m->meet.arrive(rc_trace != PTAMD_OK, n)) {
+      (void)hipStreamSynchronize(m->stream[(size_t)r]);
+      if (rc_trace == PTAMD_OK) err = "another GPU's part of the frame failed";
+      return rc_trace != PTAMD_OK ? rc_trace : (int)PTAMD_ERR_DEVICE;
+    }
+    return gather_rank(m, r, p, all, hdr_out, count_out, err);
+  });
   m->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   return rc;
 }

@@ -2410,13 +2410,13 @@ int ptamd_upload_scene(ptamd_context *c, const ptamd_scene_desc *d) {
   // visiting order (the device's primitive index).
   std::vector<int32_t> new_index(NP);
   for (int i = 0; i < NP; i++) new_index[visit_order[i]] = i;
-  // ---- The primitives at the far end of an area light's shadow rays. The CB scenes' light is a
+  // ---- The primitives at the far end of a light's shadow rays. The CB scenes' light is a
   // rectangle that coincides with an emissive quad of the geometry (to within the 5e-8 the
   // quad's float coordinates are off), and the reference's shadow rays end ON the light
   // (max_t = distToLight, pathtracer.cpp:125): whether the quad occludes such a ray is decided
   // by the last bits of an FP64 test, which no float pre-test can settle, for every shadow ray
   // of the frame. So up to four triangles that lie in a light's plane and overlap its rectangle
-  // are listed per light (the first seven area lights): k_shade runs the reference's test on them
+  // are listed per light (the first seven area or point lights that have any): k_shade runs the reference's test on them
   // when it makes a shadow ray, and the ray's walk skips the primitives that carry its light's
   // tag. Which primitives are listed only decides where they are tested, not the result: a
   // shadow ray is occluded iff some primitive's test hits strictly before its end, in any order.
@@ -2426,12 +2426,15 @@ int ptamd_upload_scene(ptamd_context *c, const ptamd_scene_desc *d) {
   {
     uint32_t next_tag = 1;
     for (int li = 0; li < d->n_lights && next_tag <= MAX_LIGHT_TAG; li++) {
-      if (d->light_kind[li] != PTAMD_LIGHT_AREA) continue;
+      // (a point light's rays end on the light as well, pathtracer.cpp:125 with light.cpp:50-57, and
+      // CBempty.dae puts one in the middle of its emissive quad: a rectangle of no extent, any plane)
+      const bool area = d->light_kind[li] == PTAMD_LIGHT_AREA;
+      if (!area && d->light_kind[li] != PTAMD_LIGHT_POINT) continue;
       const double *L = d->light_param + 16 * (size_t)li;
       const double *c0 = L + 3, *nrm = L + 6, *dx = L + 9, *dy = L + 12;
       double lo[3], hi[3], scale = 0;
       for (int k = 0; k < 3; k++) {
-        const double ex = 0.5 * (std::fabs(dx[k]) + std::fabs(dy[k]));
+        const double ex = area ? 0.5 * (std::fabs(dx[k]) + std::fabs(dy[k])) : 0.0;
         lo[k] = c0[k] - ex; hi[k] = c0[k] + ex;
         scale = std::max(scale, std::max(std::fabs(lo[k]), std::fabs(hi[k])));
       }
@@ -2442,9 +2445,17 @@ int ptamd_upload_scene(ptamd_context *c, const ptamd_scene_desc *d) {
         if (d->prim_type[p] != PTAMD_PRIM_TRIANGLE || prim_tag[p]) continue;
         const double *P = d->prim_pos + 9 * (size_t)p;
         bool in_plane = true, overlaps = true;
-        for (int v = 0; v < 3 && in_plane; v++) {
-          const double h = (P[3 * v] - c0[0]) * nrm[0] + (P[3 * v + 1] - c0[1]) * nrm[1] + (P[3 * v + 2] - c0[2]) * nrm[2];
-          in_plane = std::fabs(h) <= eps;
+        if (area) {
+          for (int v = 0; v < 3 && in_plane; v++) {
+            const double h = (P[3 * v] - c0[0]) * nrm[0] + (P[3 * v + 1] - c0[1]) * nrm[1] + (P[3 * v + 2] - c0[2]) * nrm[2];
+            in_plane = std::fabs(h) <= eps;
+          }
+        } else {
+          // the point's distance to the triangle's plane
+          const double e1[3] = {P[3] - P[0], P[4] - P[1], P[5] - P[2]}, e2[3] = {P[6] - P[0], P[7] - P[1], P[8] - P[2]};
+          const double nx = e1[1] * e2[2] - e1[2] * e2[1], ny = e1[2] * e2[0] - e1[0] * e2[2], nz = e1[0] * e2[1] - e1[1] * e2[0];
+          const double len = std::sqrt(nx * nx + ny * ny + nz * nz);
+          in_plane = len > 0 && std::fabs((c0[0] - P[0]) * nx + (c0[1] - P[1]) * ny + (c0[2] - P[2]) * nz) <= eps * len;
         }
         if (!in_plane) continue;
         for (int k = 0; k < 3; k++) {

@@ -49,7 +49,9 @@ def knot_mesh(nu, nv):
     return pts.astype(np.float32), tris
 
 
-def write_scene(kind, out_path):
+def write_scene(kind, out_path, area_light=True):
+    """area_light=False keeps CBempty.dae's own light element, a point light: the scene the first
+    round of measurements used."""
     nu, nv = PRESETS[kind]
     pts, tris = knot_mesh(nu, nv)
     with open(os.path.join(ROOT, "scenes", "CBempty.dae")) as f:
@@ -124,7 +126,8 @@ def write_scene(kind, out_path):
 """
     if dae.count(point_light) != 1:
         raise SystemExit("scenes/CBempty.dae: light element not found")
-    dae = dae.replace(point_light, point_light + area_extra, 1)
+    if area_light:
+        dae = dae.replace(point_light, point_light + area_extra, 1)
     dae = dae.replace("  </library_effects>", effect + "  </library_effects>", 1)
     dae = dae.replace("  </library_materials>", material + "  </library_materials>", 1)
     dae = dae.replace("  </library_geometries>", geometry + "  </library_geometries>", 1)
@@ -137,18 +140,19 @@ def write_scene(kind, out_path):
     return len(tris)
 
 
-def standin_path(kind):
-    return os.path.join(ROOT, "scenes", "_generated", "CB%s_standin.dae" % kind)
+def standin_path(kind, area_light=True):
+    return os.path.join(ROOT, "scenes", "_generated", "CB%s_standin%s.dae" % (kind, "" if area_light else "_pointlight"))
 
 
-def ensure(kind):
-    path = standin_path(kind)
+def ensure(kind, area_light=True):
+    path = standin_path(kind, area_light)
     stale = True
     if os.path.exists(path):
         with open(path) as f:
-            stale = "<area>" not in f.read(4096)  # a file written before the light became an area light
+            # (a file written before the light became an area light is stale)
+            stale = ("<area>" in f.read(4096)) != area_light
     if stale:
-        write_scene(kind, path)
+        write_scene(kind, path, area_light)
     return path
 
 

@@ -45,10 +45,11 @@ namespace {
 // ------------------------------------------------------------------ device data
 // 4-wide BVH node in 64 bytes (half an L2 line): the four child boxes are 8-bit
 // offsets on a per-node power-of-two grid, plus four child codes. The tree is the
-// reference's binary SAH tree collapsed two levels at a time, with every
-// primitive as its own child (so each primitive is culled by its own box before
-// its own test). A code >= 0 is a node index, a negative code is primitive
-// ~code, CHILD_EMPTY marks an unused slot.
+// reference's binary SAH tree collapsed (a node's children are opened, largest box
+// first, while the result fits four slots), with every primitive as its own child
+// (so each primitive is culled by its own box before its own test). A code >= 0 is
+// a node index, a negative code other than CHILD_EMPTY (an unused slot) is a
+// primitive: ~code = primitive | light tag << 24 (PRIM_BITS below).
 //
 // Why so small: the traversal kernels are bound by the number of 16-byte
 // per-lane loads the vector L1 can serve for divergent addresses (TCP and TD

@@ -312,13 +312,8 @@ __device__ __forceinline__ RayF make_rayf(v3 d) {
 #ifndef PTAMD_STACK_SHADOW
 #define PTAMD_STACK_SHADOW 10  // 7 workgroups per CU x 22 KiB
 #endif
-// Build-time tuning of the traversal kernels (defaults are the measured best):
-// resident waves per SIMD the register allocator must make room for (0: its own
-// choice; 6 costs a few spilled registers and still wins, 7 loses, 8 does not
-// compile), workgroups launched per resident workgroup slot.
-#ifndef PTAMD_WAVES_PER_EU
-#define PTAMD_WAVES_PER_EU 6
-#endif
+// Build-time tuning of the traversal kernels (defaults are the measured best): workgroups
+// launched per resident workgroup slot by the grid-stride driver (REFILL == 0),
 #ifndef PTAMD_GRID_MULT
 #define PTAMD_GRID_MULT 8
 #endif
@@ -718,7 +713,7 @@ struct Walk {
 //    bounce rays PROVIDED the kernel does not spill: the bookkeeping costs about
 //    ten registers, and with spills in the loop the same driver was 30 to 90 %
 //    slower than the grid-stride one. Hence closest-hit walks run at 5 waves per
-//    SIMD (no spills) and any-hit walks, which carry less state, at 6.
+//    SIMD (no spills) and first-hit walks, which carry less state, at 7.
 //
 // Also measured and rejected: claims that shrink towards the end of the list (guided
 // self-scheduling, so that no wave holds unstarted rays while others idle): 7 % slower, a
@@ -1366,8 +1361,8 @@ struct Compact {
 // ray's hit). Restates at_least_one_bounce_radiance (pathtracer.cpp:160-201)
 // iteratively: the path carries its throughput T, every shaded vertex adds
 // T * direct light.
-// (135 VGPRs, 3 waves per SIMD. Forcing 4 waves was measured slower: the kernel is
-// bound by the bytes it moves, about 3.6 TB/s of HBM traffic, not by latency.)
+// (131 VGPRs, 3 waves per SIMD. Forcing 4 waves (127 registers, 2 spilled) gains 0.5 % at
+// most: the kernel is bound by its FP64 arithmetic and the bytes it moves, not by latency.)
 template <bool HEMI>
 __global__ void __launch_bounds__(256)
     k_shade(FrameParams fp, DevScene S, RayQ q, const int32_t *__restrict__ list, HitBuf hb, RayQ qn, ShadowQ sq,

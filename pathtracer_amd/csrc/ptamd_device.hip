@@ -69,7 +69,7 @@ namespace {
 // instead of ordering two distances per child and axis.
 struct alignas(64) DevNode {
   float org[3];
-  uint32_t exps;    // byte k: e_k as a signed 8-bit integer
+  uint32_t exps;    // bytes 0..2: e_k as signed 8-bit integers; byte 3: the light tag its tagged primitive children carry (0: none, or not all the same)
   uint32_t qlo[3];  // per axis: lower planes of children 0..3
   uint32_t qhi[3];  // per axis: upper planes
   int32_t child[4];
@@ -327,6 +327,9 @@ __device__ __forceinline__ RayF make_rayf(v3 d) {
 #ifndef PTAMD_NODE_STEPS
 #define PTAMD_NODE_STEPS 2
 #endif
+#ifndef PTAMD_NODE_TAGS
+#define PTAMD_NODE_TAGS 1  // end primitives are rejected in the box step of the node that holds them (see node_step)
+#endif
 // idle lanes at which a persistent wave refills (0: grid-stride driver), see trace_rays
 #ifndef PTAMD_REFILL_EXTEND
 #define PTAMD_REFILL_EXTEND 24
@@ -558,6 +561,19 @@ struct Walk {
       const float hi2 = fminf(fminf(fminf(tf[0], tf[1]), tf[2]), best_f);
       t[k] = (c[k] != CHILD_EMPTY && !(lo2 > hi2)) ? lo2 : FINF;
     }
+#if PTAMD_NODE_TAGS
+    // A node some of whose children are end primitives of the light this shadow ray goes to (k_shade has
+    // tested them): they are passed over here, before they cost the lane a trip each. The node's header
+    // names the tag, so the other nodes pay one comparison.
+    {
+      const uint32_t ntag = w0.w >> 24;
+      if (ntag != 0u && ntag == (skip >> PRIM_BITS & MAX_LIGHT_TAG)) {
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+          if ((~(uint32_t)c[k] >> PRIM_BITS) == ntag) t[k] = FINF;
+      }
+    }
+#endif
     if (in_order) {
       const int a0 = t[0] < FINF, a1 = t[1] < FINF, a2 = t[2] < FINF, a3 = t[3] < FINF;
       const int n01 = a0 + a1, n012 = n01 + a2, nacc = n012 + a3;
@@ -2571,6 +2587,17 @@ int ptamd_upload_scene(ptamd_context *c, const ptamd_scene_desc *d) {
     if (!quantize_node(nodes[f.node4], boxes, (int)kids.size())) {
       ptamd::set_error("BVH node box cannot be represented (non-finite or out of float range)");
       return PTAMD_ERR_SCENE;
+    }
+    {
+      // the light tag of the node's tagged primitive children, if they agree on one
+      uint32_t ntag = 0;
+      bool agree = true;
+      for (size_t k = 0; k < kids.size(); k++)
+        if (kids[k].node < 0 && prim_tag[kids[k].prim]) {
+          if (ntag && ntag != prim_tag[kids[k].prim]) agree = false;
+          ntag = prim_tag[kids[k].prim];
+        }
+      nodes[f.node4].exps = (nodes[f.node4].exps & 0x00ffffffu) | ((agree ? ntag : 0u) << 24);
     }
     for (size_t k = 0; k < kids.size(); k++) {
       if (kids[k].node < 0) {

@@ -1,0 +1,35 @@
+"""The benchmark's roofline figures are recomputed from the counter summaries committed under
+profiles/: the files bench.py will pick up must hold what it reads, and the figure they give
+must be a fraction. CPU only."""
+import glob
+import json
+import os
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+@pytest.mark.parametrize("scene", ["dragon", "bunny"])
+def test_latest_profile_summary_feeds_the_roofline(scene):
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_summary.json" % scene)))
+    assert found, "no committed profile summary for %s" % scene
+    d = json.load(open(found[-1]))
+    for kernel in ("shadow", "trace2", "extend", "shade", "resolve"):
+        pc = bench.profiled_counters(scene, kernel)
+        assert pc is not None and pc["source"].endswith(os.path.basename(found[-1]))
+        t = pc["trace_avg_launch_ms"] * 1e-3
+        frac = pc["lane_ops_per_launch"] / t / 1e12 / bench.LANE_OPS_PEAK_T
+        assert 0 < frac <= 1, (kernel, frac)
+        assert 0 < pc["lane_ops_per_launch"] <= 64 * pc["valu_insts_per_launch"]  # at most 64 lanes per instruction
+        tr, src = bench.profiled_traffic(scene, kernel)
+        assert tr and tr > 0 and src == pc["source"]
+        # measured HBM traffic below the 8 TB/s the card can move in that time
+        assert tr / t / 1e9 < bench.HBM_PEAK_GBS
+    # the run the summary was made from reported the kernel the counters are scaled by
+    assert d["bench"]["roofline"]["kernel"] in bench.KERNEL_NAMES
+    assert d["bench"]["roofline"].get("rays_per_launch", 0) > 0 or d["bench"]["roofline"]["kernel"] in ("shade", "resolve")

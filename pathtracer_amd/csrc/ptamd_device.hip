@@ -2017,7 +2017,7 @@ struct ptamd_context {
   bool clear_ctl = false;  // the next ptamd_trace_list zeroes the device-side counters first
   double plan_margin = 1.5;  // RoundPlan::margin (PTAMD_PLAN_MARGIN in the environment: experiments)
   bool trace_two = true;  // bounce rays of depth d + 1 and shadow rays of depth d in one launch (PTAMD_TRACE_TWO=0: apart)
-  uint32_t fuse_below = 6u << 20;  // ... when the two lists together are shorter than this (PTAMD_FUSE_BELOW)
+  uint32_t fuse_below = 16u << 20;  // ... when the two lists together are shorter than this (PTAMD_FUSE_BELOW)
   int64_t max_paths = 16 << 20;  // paths per launch: large launches amortise the drain of the slowest waves
   int64_t cap_paths = 0;
   int cap_nls = 0;

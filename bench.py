@@ -48,7 +48,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--scene", default="dragon", help="dragon (stand-in), dragon-point (the stand-in with a point light: round 1's workload), bunny, spheres, or a .dae path")
+    ap.add_argument("--scene", default="dragon", help="dragon (stand-in), dragon-point (the stand-in with CBempty.dae's own point light: the earlier headline workload), bunny, spheres, or a .dae path")
     ap.add_argument("--specular", action="store_true",
                     help="ideal mirror / glass instead of the reference's black stubs (the divergent-specular "
                          "stress: --scene spheres --specular --depth 16)")
@@ -84,12 +84,12 @@ def resolve_scene(name, rank):
         return path, ("CBdragon stand-in (CBempty box with the CB scenes' area light + 100k-triangle procedural knot; "
                       "CBdragon.dae is absent from the reference checkout)"), 1024
     if name == "dragon-point":
-        # the first round's headline workload, kept for like-for-like comparisons: the same geometry with
+        # the headline workload of earlier measurements, kept for like-for-like comparisons: the same geometry with
         # CBempty.dae's own light, a point light (one shadow ray per vertex whatever -l says)
         path = make_standin_scene.standin_path("dragon", area_light=False)
         if rank == 0:
             make_standin_scene.ensure("dragon", area_light=False)
-        return path, "CBdragon stand-in with CBempty.dae's point light (round 1's workload)", 1024
+        return path, "CBdragon stand-in with CBempty.dae's own point light (the earlier headline workload)", 1024
     if name == "bunny":
         return os.path.join(ROOT, "scenes", "CBbunny.dae"), "CBbunny.dae", 256
     if name == "spheres":

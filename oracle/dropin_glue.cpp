@@ -2,8 +2,8 @@
 // loader, scene objects, BVHAccel build, Camera, RaytracedRenderer) with ONE member function
 // replaced, RaytracedRenderer::start_raytracing (src/pathtracer/raytraced_renderer.cpp:268-329),
 // which here hands the frame to libptamd.so through the C ABI instead of filling the tile queue
-// and starting worker threads. It is the binding a maintainer of the reference would add
-// (INTEGRATION.md shows the same code as a patch), built by `make -C oracle dropin`: the
+// and starting worker threads. It is the binding a maintainer of the reference would add,
+// built by `make -C oracle dropin`: the
 // reference's translation units are compiled unmodified where they lie; the object of
 // raytraced_renderer.cpp gets its start_raytracing symbol weakened (objcopy) so that the
 // definition below takes its place at link time.

@@ -50,8 +50,8 @@ def knot_mesh(nu, nv):
 
 
 def write_scene(kind, out_path, area_light=True):
-    """area_light=False keeps CBempty.dae's own light element, a point light: the scene the first
-    round of measurements used."""
+    """area_light=False keeps CBempty.dae's own light element, a point light (the scene of the earliest
+    measurements)."""
     nu, nv = PRESETS[kind]
     pts, tris = knot_mesh(nu, nv)
     with open(os.path.join(ROOT, "scenes", "CBempty.dae")) as f:

@@ -4,6 +4,7 @@ length lives on the device, sharded tracing, and the pack / unpack exchange.
 Several ranks are emulated on ONE GPU: every virtual rank has its own copy of the
 per-pixel state, traces its shard of each round's list, and the ranks' packed
 blocks are concatenated exactly as an all-gather would lay them out."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -147,6 +148,12 @@ def test_list_argument_errors(device):
     device.trace_list(cabi.PixelList(buf.data_ptr(), 0, 1, 1, 3, 4), 0, 4, state.data_ptr())
 
 
+# (both tests below look at the default launch policy; a run that overrides it through the
+# environment, as the A/B scripts do, has nothing to check here)
+_POLICY_OVERRIDDEN = any(k in os.environ for k in ("PTAMD_FUSE_BELOW", "PTAMD_TRACE_TWO"))
+
+
+@pytest.mark.skipif(_POLICY_OVERRIDDEN, reason="launch policy overridden in the environment")
 def test_fused_and_separate_traversal_launches_give_the_same_frame(device, monkeypatch):
     """k_trace2 (bounce rays of depth d + 1 and shadow rays of depth d in one launch) against one
     launch per kind (PTAMD_TRACE_TWO=0, read when a context is created): which lane traces a ray,
@@ -184,6 +191,7 @@ def test_fused_and_separate_traversal_launches_give_the_same_frame(device, monke
     assert np.array_equal(cnt_f, cnt_s) and np.array_equal(hdr_f, hdr_s)
 
 
+@pytest.mark.skipif(_POLICY_OVERRIDDEN, reason="launch policy overridden in the environment")
 def test_event_classes_restrict_what_is_timed(device):
     p = _setup(device)
     device.set_profiling(events=True, counters=False)

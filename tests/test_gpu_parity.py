@@ -299,6 +299,32 @@ def test_primary_hits_match_reference_golden(device, name, w, h):
         assert hashlib.sha256(ts.tobytes()).digest() == g["t_sha256_%d" % o].tobytes()
 
 
+@pytest.mark.parametrize("name,w,h", [("CBbunny", 800, 600), ("standin:dragon", 800, 600), ("standin:lucy", 1920, 1080)])
+def test_primary_hits_match_reference_golden_at_benchmark_sizes(device, name, w, h):
+    """The same bar on the frames of the benchmark table's configurations 2, 3 (the headline) and 4, at their
+    full sizes: ids of every pixel against the reference's own BVHAccel::intersect, t bit for bit."""
+    if name.startswith("standin:"):
+        sys.path.insert(0, os.path.join(os.path.dirname(GOLDEN), "..", "tools"))
+        import make_standin_scene
+        which = name.split(":")[1]
+        sc = pt.Scene(make_standin_scene.ensure(which))
+        gname = "CB%s_standin" % which
+    else:
+        sc = pt.Scene(scene_path(name))
+        gname = name
+    g = np.load(os.path.join(GOLDEN, "primary_%s_%dx%d.npz" % (gname, w, h)))
+    device.upload(sc)
+    device.set_camera(sc.camera(w, h))
+    offs = g["offsets"].reshape(4, 2)
+    for o in range(4):
+        sx, sy = _sensor_grid(w, h, offs[o])
+        ids, ts = device.trace_primary(sx, sy)
+        same = (ids == g["ids_%d" % o]).mean()
+        assert same >= 0.9999, "only %.5f%% of ids match" % (100 * same)
+        assert same == 1.0
+        assert hashlib.sha256(ts.tobytes()).digest() == g["t_sha256_%d" % o].tobytes()
+
+
 def _blocks(img, b=8):
     h, w, c = img.shape
     return img[:h - h % b, :w - w % b].reshape(h // b, b, w // b, b, c).mean(axis=(1, 3))

@@ -1,6 +1,7 @@
 """Pins the CPU oracle against outputs of the reference itself (tests/golden, written
 by tools/make_golden.py from the reference's own sources). CPU only."""
 import hashlib
+import sys
 import os
 
 import numpy as np
@@ -80,6 +81,33 @@ def test_primary_hits_bit_exact(name, w, h):
             # fov recomputed through numpy's arctan may differ from libm's by an ulp
             assert (ids == g["ids_%d" % o]).mean() >= 0.9999
             assert np.allclose(ts[::97], g["t_sub_%d" % o], rtol=1e-12, atol=0)
+
+
+@pytest.mark.parametrize("name,w,h", [("CBbunny", 800, 600), ("standin:dragon", 800, 600), ("standin:lucy", 1920, 1080)])
+def test_primary_hits_bit_exact_at_benchmark_sizes(name, w, h):
+    """The frames of the benchmark table's configurations 2, 3 and 4 (3 and 4: the stand-ins for the absent
+    CBdragon.dae / CBlucy.dae): primitive ids of EVERY pixel and t bit for bit against the reference's own
+    BVHAccel::intersect, four sub-pixel offsets. Scene arrays and camera come from the product loader, which
+    tests/test_host_pipeline.py shows to be the reference's bit for bit."""
+    import pathtracer_amd as pt
+    from conftest import scene_path
+    if name.startswith("standin:"):
+        sys.path.insert(0, os.path.join(os.path.dirname(GOLDEN), "..", "tools"))
+        import make_standin_scene
+        which = name.split(":")[1]
+        sc = pt.Scene(make_standin_scene.ensure(which))
+        gname = "CB%s_standin" % which
+    else:
+        sc = pt.Scene(scene_path(name))
+        gname = name
+    g = np.load(_g("primary_%s_%dx%d.npz" % (gname, w, h)))
+    arr, cam = sc.arrays(), sc.camera(w, h)
+    ys, xs = np.mgrid[0:h, 0:w]
+    offs = g["offsets"].reshape(4, 2)
+    for o in range(4):
+        ids, ts = O.trace_primary(arr, cam, ((xs + offs[o, 0]) / w).ravel(), ((ys + offs[o, 1]) / h).ravel())
+        assert np.array_equal(ids, g["ids_%d" % o]), "%d ids differ" % int((ids != g["ids_%d" % o]).sum())
+        assert hashlib.sha256(ts.tobytes()).digest() == g["t_sha256_%d" % o].tobytes()
 
 
 def _blocks(img, b=8):

@@ -82,8 +82,12 @@ def scene_and_primary_goldens(sc):
                 ptar.save(os.path.join(GOLD, "scene_%s.ptar" % name), {k: a[k] for k in SCENE_ARRAYS})
     json.dump(hashes, open(os.path.join(GOLD, "scene_hashes.json"), "w"), indent=0, sort_keys=True)
 
-    for name, w, h in (("CBspheres_lambertian", 480, 360), ("CBspheres", 240, 180), ("CBgems", 240, 180),
-                       ("CBbunny", 200, 150), ("CBcoil", 160, 120), ("cube", 96, 72)):
+    primary_goldens(sc, (("CBspheres_lambertian", 480, 360), ("CBspheres", 240, 180), ("CBgems", 240, 180),
+                         ("CBbunny", 200, 150), ("CBcoil", 160, 120), ("cube", 96, 72)))
+
+
+def primary_goldens(sc, jobs):
+    for name, w, h in jobs:
         out = os.path.join(TMP, "p.ptar")
         run(["primary", "-r", str(w), str(h), "-f", out, sc[name]])
         a = ptar.load(out)
@@ -95,6 +99,16 @@ def scene_and_primary_goldens(sc):
             rec["t_sub_%d" % o] = a["primary_t_%d" % o][::97]
         np.savez_compressed(os.path.join(GOLD, "primary_%s_%dx%d.npz" % (name, w, h)), **rec)
 
+
+
+def primary_goldens_full_size():
+    """Primary hits at the sizes of the benchmark table's configurations 2, 3 and 4 (3 and 4 on the
+    stand-ins for the absent CBdragon.dae / CBlucy.dae), every pixel, four sub-pixel offsets."""
+    import make_standin_scene
+    sc = dict(scenes())
+    sc["CBdragon_standin"] = make_standin_scene.ensure("dragon")
+    sc["CBlucy_standin"] = make_standin_scene.ensure("lucy")
+    primary_goldens(sc, (("CBbunny", 800, 600), ("CBdragon_standin", 800, 600), ("CBlucy_standin", 1920, 1080)))
 
 
 def render_goldens(sc):
@@ -175,9 +189,14 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "renders":
         os.makedirs(TMP, exist_ok=True)
         main(only_renders=True)
+    elif len(sys.argv) > 1 and sys.argv[1] == "primary_full":
+        os.makedirs(TMP, exist_ok=True)
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        primary_goldens_full_size()
     elif len(sys.argv) > 1 and sys.argv[1] == "blocks":
         os.makedirs(TMP, exist_ok=True)
         block_goldens(sys.argv[2] if len(sys.argv) > 2 else None)
     else:
         main()
+        primary_goldens_full_size()
         block_goldens()

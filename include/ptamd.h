@@ -274,7 +274,8 @@ int ptamd_filter_list(ptamd_context *ctx, const ptamd_pixel_list *in, int32_t n_
  * ends) instead of a buffer the library grows on demand, and the call makes no
  * hipMalloc / hipFree / event creation. Lists longer than PTAMD_FILTER_STATIC_MAX_PIXELS
  * entries (n_max, after offset / stride) are rejected with PTAMD_ERR_ARG. All calls on one
- * GPU share that array: two calls that overlap in time on the same GPU race. */
+ * GPU share that array: two calls that overlap in time on the same GPU race. Its launches are counted in
+ * ptamd_stats.launches[PTAMD_K_FILTER] but, creating no events, add nothing to kernel_ms. */
 #define PTAMD_FILTER_STATIC_MAX_PIXELS (4 * 1024 * 1024)
 int ptamd_filter_list_static(ptamd_context *ctx, const ptamd_pixel_list *in, int32_t n_done,
                              const double *d_state, int32_t *d_pixels_out, int64_t *d_n_out, void *stream);
@@ -303,6 +304,11 @@ int ptamd_frame_resolve(ptamd_context *ctx, const double *d_state, double *d_hdr
  * ptamd_render runs on the whole rectangle. */
 int ptamd_render_list(ptamd_context *ctx, const ptamd_render_params *params, const int32_t *d_pixels, int64_t n,
                       double *d_state, void *stream);
+/* Ordering: ptamd_render_list returns with its last rounds still queued and keeps, per context, the
+ * survivor lists, their lengths and the work buffers those rounds use. Calls of ptamd_render_list,
+ * ptamd_render, ptamd_trace_list and ptamd_trace_primary on ONE context must therefore reach the device in
+ * order: issue them on the same stream, or synchronise with the earlier call's stream before the next
+ * call. (A later call that needs larger buffers synchronises the whole device before it frees the old ones.) */
 
 int ptamd_get_stats(ptamd_context *ctx, ptamd_stats *out);
 
@@ -318,6 +324,8 @@ void ptamd_multi_destroy(ptamd_multi *m);
 int32_t ptamd_multi_size(const ptamd_multi *m);
 int ptamd_multi_upload_scene(ptamd_multi *m, const ptamd_scene_desc *desc);
 int ptamd_multi_set_camera(ptamd_multi *m, const ptamd_camera *cam);
+/* ptamd_set_profiling on every GPU (the CLI's -C together with -g) */
+int ptamd_multi_set_profiling(ptamd_multi *m, int32_t events, int32_t counters);
 /* as ptamd_render */
 int ptamd_multi_render(ptamd_multi *m, const ptamd_render_params *params, double *hdr_out, int32_t *count_out);
 /* statistics of one GPU's share; seconds = wall time of the whole frame */

@@ -85,10 +85,28 @@ def lib():
 
 EXPORTS_MULTI = (
     "ptamd_multi_create", "ptamd_multi_destroy", "ptamd_multi_size", "ptamd_multi_upload_scene",
-    "ptamd_multi_set_camera", "ptamd_multi_render", "ptamd_multi_get_stats", "ptamd_multi_shard_size",
-    "ptamd_multi_rows_per_rank",
+    "ptamd_multi_set_camera", "ptamd_multi_set_profiling", "ptamd_multi_render", "ptamd_multi_get_stats",
+    "ptamd_multi_shard_size", "ptamd_multi_rows_per_rank",
 )
 _LIB_MULTI = None
+
+
+def _declare_multi(M):
+    vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
+    M.ptamd_multi_create.argtypes = [C.POINTER(i32), i32, C.POINTER(vp)]
+    M.ptamd_multi_destroy.argtypes = [vp]
+    M.ptamd_multi_destroy.restype = None
+    M.ptamd_multi_size.argtypes = [vp]
+    M.ptamd_multi_upload_scene.argtypes = [vp, C.POINTER(SceneDesc)]
+    M.ptamd_multi_set_camera.argtypes = [vp, C.POINTER(Camera)]
+    M.ptamd_multi_set_profiling.argtypes = [vp, i32, i32]
+    M.ptamd_multi_render.argtypes = [vp, C.POINTER(RenderParams), C.POINTER(C.c_double), C.POINTER(C.c_int32)]
+    M.ptamd_multi_get_stats.argtypes = [vp, i32, C.POINTER(Stats)]
+    M.ptamd_multi_shard_size.argtypes = [i64, i32, i32]
+    M.ptamd_multi_shard_size.restype = i64
+    M.ptamd_multi_rows_per_rank.argtypes = [i64, i32]
+    M.ptamd_multi_rows_per_rank.restype = i64
+    return M
 
 
 def lib_multi():
@@ -106,20 +124,7 @@ def lib_multi():
     path = os.path.join(os.path.dirname(lib_path()), "libptamd_multi.so")
     if not os.path.exists(path):
         raise PtamdError("%s is missing: build it with `make -C pathtracer_amd/csrc`" % path)
-    M = C.CDLL(path, mode=C.RTLD_GLOBAL)
-    vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
-    M.ptamd_multi_create.argtypes = [C.POINTER(i32), i32, C.POINTER(vp)]
-    M.ptamd_multi_destroy.argtypes = [vp]
-    M.ptamd_multi_destroy.restype = None
-    M.ptamd_multi_size.argtypes = [vp]
-    M.ptamd_multi_upload_scene.argtypes = [vp, C.POINTER(SceneDesc)]
-    M.ptamd_multi_set_camera.argtypes = [vp, C.POINTER(Camera)]
-    M.ptamd_multi_render.argtypes = [vp, C.POINTER(RenderParams), C.POINTER(C.c_double), C.POINTER(C.c_int32)]
-    M.ptamd_multi_get_stats.argtypes = [vp, i32, C.POINTER(Stats)]
-    M.ptamd_multi_shard_size.argtypes = [i64, i32, i32]
-    M.ptamd_multi_shard_size.restype = i64
-    M.ptamd_multi_rows_per_rank.argtypes = [i64, i32]
-    M.ptamd_multi_rows_per_rank.restype = i64
+    M = _declare_multi(C.CDLL(path, mode=C.RTLD_GLOBAL))
     _LIB_MULTI = M
     return M
 
@@ -172,35 +177,41 @@ class Scene:
 class MultiDevice:
     """Several GPUs of this node rendering a frame together (ptamd_multi_*, C++ threads + RCCL)."""
 
-    def __init__(self, device_ids):
+    def __init__(self, device_ids, library=None):
+        """library: another build of libptamd_multi.so, already loaded and declared (the tests' build with an
+        in-process stand-in for RCCL); default: libptamd_multi.so."""
+        self._m = library or lib_multi()
         ids = (C.c_int32 * len(device_ids))(*device_ids)
         self._h = C.c_void_p()
-        _check(lib_multi().ptamd_multi_create(ids, len(device_ids), C.byref(self._h)))
+        _check(self._m.ptamd_multi_create(ids, len(device_ids), C.byref(self._h)))
         self._keep = None
+
+    def set_profiling(self, events=False, counters=False):
+        _check(self._m.ptamd_multi_set_profiling(self._h, int(events), int(counters)))
 
     def upload(self, scene):
         desc = scene.desc if hasattr(scene, "desc") else scene
         self._keep = scene
-        _check(lib_multi().ptamd_multi_upload_scene(self._h, C.byref(desc)))
+        _check(self._m.ptamd_multi_upload_scene(self._h, C.byref(desc)))
 
     def set_camera(self, cam):
-        _check(lib_multi().ptamd_multi_set_camera(self._h, C.byref(cam)))
+        _check(self._m.ptamd_multi_set_camera(self._h, C.byref(cam)))
 
     def render(self, params):
         hdr = np.zeros((params.h, params.w, 3), np.float64)
         cnt = np.zeros((params.h, params.w), np.int32)
-        _check(lib_multi().ptamd_multi_render(self._h, C.byref(params), hdr.ctypes.data_as(C.POINTER(C.c_double)),
+        _check(self._m.ptamd_multi_render(self._h, C.byref(params), hdr.ctypes.data_as(C.POINTER(C.c_double)),
                                               cnt.ctypes.data_as(C.POINTER(C.c_int32))))
         return hdr, cnt
 
     def stats(self, rank=0):
         st = Stats()
-        _check(lib_multi().ptamd_multi_get_stats(self._h, rank, C.byref(st)))
+        _check(self._m.ptamd_multi_get_stats(self._h, rank, C.byref(st)))
         return st
 
     def close(self):
         if self._h:
-            lib_multi().ptamd_multi_destroy(self._h)
+            self._m.ptamd_multi_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

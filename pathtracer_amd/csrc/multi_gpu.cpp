@@ -25,6 +25,15 @@
 #include "../../include/ptamd.h"
 #include "error_state.h"
 
+// PTAMD_MULTI_TEST_HOOKS is defined only by the TEST build of this file (tests/_build/libptamd_multi_fake.so,
+// `make -C pathtracer_amd/csrc test_multi`), which also swaps RCCL for an in-process stand-in: several logical
+// ranks may then share one physical GPU, and a test can make one rank's part of a frame fail. libptamd_multi.so
+// is built without it.
+#ifdef PTAMD_MULTI_TEST_HOOKS
+#include <atomic>
+static std::atomic<int> g_test_fail_rank{-1};
+#endif
+
 // Where the host threads of a frame meet before the exchange: a GPU whose part failed must not
 // leave the others waiting in a send or receive that will never be matched.
 struct Rendezvous {
@@ -109,6 +118,12 @@ int trace_rank(ptamd_multi *m, int r, const ptamd_render_params *p, const std::v
   ptamd_multi::PerGpu &g = m->gpu[r];
   hipStream_t s = m->stream[r];
   M_HIP(hipSetDevice(m->devices[r]));
+#ifdef PTAMD_MULTI_TEST_HOOKS
+  {
+    int want = r;
+    if (g_test_fail_rank.compare_exchange_strong(want, -1)) { err = "failure injected by the test"; return PTAMD_ERR_DEVICE; }
+  }
+#endif
   const int64_t npix = (int64_t)p->w * p->h, n_all = (int64_t)all.size();
   const int64_t n_mine = ptamd_multi_shard_size(n_all, r, n), rows = ptamd_multi_rows_per_rank(n_all, n);
   if (int rc = grow(&g.d_all, &g.cap_all, n_all, err)) return rc;
@@ -196,9 +211,11 @@ int64_t ptamd_multi_rows_per_rank(int64_t n, int32_t world) {
 
 int ptamd_multi_create(const int32_t *device_ids, int32_t n, ptamd_multi **out) {
   if (!device_ids || n < 1 || !out) { ptamd::set_error("invalid arguments to ptamd_multi_create"); return PTAMD_ERR_ARG; }
+#ifndef PTAMD_MULTI_TEST_HOOKS
   for (int a = 0; a < n; a++)
     for (int b = a + 1; b < n; b++)
       if (device_ids[a] == device_ids[b]) { ptamd::set_error("ptamd_multi_create: a device is listed twice"); return PTAMD_ERR_ARG; }
+#endif
   ptamd_multi *m = new ptamd_multi;
   m->devices.assign(device_ids, device_ids + n);
   m->gpu.resize((size_t)n);
@@ -264,6 +281,15 @@ int ptamd_multi_set_camera(ptamd_multi *m, const ptamd_camera *cam) {
   return PTAMD_OK;
 }
 
+int ptamd_multi_set_profiling(ptamd_multi *m, int32_t events, int32_t counters) {
+  if (!m) { ptamd::set_error("null argument"); return PTAMD_ERR_ARG; }
+  for (ptamd_context *c : m->ctx) {
+    const int rc = ptamd_set_profiling(c, events, counters);
+    if (rc) return rc;
+  }
+  return PTAMD_OK;
+}
+
 int ptamd_multi_render(ptamd_multi *m, const ptamd_render_params *p, double *hdr_out, int32_t *count_out) {
   if (!m || !p || !hdr_out || !count_out || p->w <= 0 || p->h <= 0) { ptamd::set_error("invalid arguments to ptamd_multi_render"); return PTAMD_ERR_ARG; }
   const int n = (int)m->ctx.size();
@@ -304,5 +330,27 @@ int ptamd_multi_get_stats(ptamd_multi *m, int32_t rank, ptamd_stats *out) {
   if (!rc) out->seconds = m->seconds;  // the frame's wall time, uploads of the pixel lists and the gather included
   return rc;
 }
+
+#ifdef PTAMD_MULTI_TEST_HOOKS
+// the next frame's part of logical rank `rank` fails before it starts (-1: nobody's)
+void ptamd_multi_test_fail_rank(int32_t rank) { g_test_fail_rank.store(rank); }
+// Rendezvous::arrive with n threads over `generations` meetings, thread `failing` (or nobody: -1) reporting a
+// failure in meeting `failing_generation`: returns 0 if every thread of every meeting got that meeting's
+// verdict (true exactly in the failing one), i.e. a failure releases everybody and does not leak into the next
+int32_t ptamd_multi_test_rendezvous(int32_t n, int32_t generations, int32_t failing, int32_t failing_generation) {
+  Rendezvous meet;
+  std::atomic<int> wrong{0};
+  std::vector<std::thread> th;
+  for (int t = 0; t < n; t++)
+    th.emplace_back([&, t]() {
+      for (int g = 0; g < generations; g++) {
+        const bool verdict = meet.arrive(t == failing && g == failing_generation, n);
+        if (verdict != (failing >= 0 && failing < n && g == failing_generation)) wrong++;
+      }
+    });
+  for (auto &t : th) t.join();
+  return wrong.load();
+}
+#endif
 
 }  // extern "C"

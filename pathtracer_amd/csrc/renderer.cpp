@@ -67,6 +67,7 @@ struct MultiGpu {
   int (*set_camera)(ptamd_multi *, const ptamd_camera *) = nullptr;
   int (*render)(ptamd_multi *, const ptamd_render_params *, double *, int32_t *) = nullptr;
   int (*get_stats)(ptamd_multi *, int32_t, ptamd_stats *) = nullptr;
+  int (*set_profiling)(ptamd_multi *, int32_t, int32_t) = nullptr;
   std::vector<int32_t> devices;
   ~MultiGpu() {
     if (h && destroy) destroy(h);
@@ -89,7 +90,8 @@ struct MultiGpu {
     set_camera = (decltype(set_camera))dlsym(lib, "ptamd_multi_set_camera");
     render = (decltype(render))dlsym(lib, "ptamd_multi_render");
     get_stats = (decltype(get_stats))dlsym(lib, "ptamd_multi_get_stats");
-    if (!create || !destroy || !upload_scene || !set_camera || !render || !get_stats) {
+    set_profiling = (decltype(set_profiling))dlsym(lib, "ptamd_multi_set_profiling");
+    if (!create || !destroy || !upload_scene || !set_camera || !render || !get_stats || !set_profiling) {
       error = path + " lacks an entry point";
       return false;
     }
@@ -253,7 +255,7 @@ void RaytracedRenderer::start_raytracing() {  // raytraced_renderer.cpp:268-329
   pt->camera = camera;
   pt->scene = scene;
   int rc = multi ? multi->set_camera(multi->h, camera) : ptamd_set_camera(bvh, camera);
-  if (!rc && !multi) rc = ptamd_set_profiling(bvh, 0, profile_counters ? 1 : 0);
+  if (!rc) rc = multi ? multi->set_profiling(multi->h, 0, profile_counters ? 1 : 0) : ptamd_set_profiling(bvh, 0, profile_counters ? 1 : 0);
   size_t x0 = 0, y0 = 0, x1 = width, y1 = height;
   if (!render_cell) {
     frameBuffer.clear();
@@ -281,6 +283,8 @@ void RaytracedRenderer::start_raytracing() {  // raytraced_renderer.cpp:268-329
       stats.seconds = part.seconds;
       stats.samples += part.samples; stats.rays += part.rays; stats.shadow_rays += part.shadow_rays;
       stats.path_vertices += part.path_vertices; stats.prim_tests += part.prim_tests; stats.nodes_visited += part.nodes_visited;
+      stats.exact_tests += part.exact_tests; stats.two_ext_rays += part.two_ext_rays; stats.two_shadow_rays += part.two_shadow_rays;
+      for (int k = 0; k < PTAMD_K_CLASSES; k++) { stats.launches[k] += part.launches[k]; stats.kernel_ms[k] += part.kernel_ms[k]; }
     }
   } else {
     ptamd_get_stats(bvh, &stats);

@@ -12,9 +12,14 @@ sampleCountBuffer would hold them. Rank 0 prints ONE JSON line.
 
 The line also carries
   roofline      for the dominant kernel (a BVH walk: bound by VALU instruction issue,
-                not by HBM). Top level: the issue ceiling, lane-operations per second
-                against 1024 SIMDs x 16 lanes x 2.4 GHz, from the committed rocprofv3
-                counter passes of this workload and the kernel's live HIP-event time.
+                not by HBM). Top level: VALU lane-operations per second against the card's
+                full-rate ceiling, 1024 SIMDs x 32 lanes x 2.4 GHz = 78.6 T/s (a wave64
+                v_fma_f32 issues every 2 cycles once a SIMD holds two or more waves: measured
+                in shader cycles, profiles/r03_valu_rates.txt), from the committed rocprofv3
+                counter passes of this workload and the kernel's live HIP-event time. The
+                fraction factors as (cycles the VALU is busy) x (what the instruction mix
+                allows: most non-FMA instructions issue every 4 cycles) x (lanes switched on),
+                reported under `issue`.
                 Beside it: `hbm_algorithmic` (bytes the REFERENCE's traversal would
                 move for the same rays, counted by the CPU restatement, over the live
                 kernel time against 8 TB/s: above 1, the GPU walk does far less work per
@@ -38,8 +43,14 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
 L2_PEAK_GBS = 34500.0  # aggregate of the eight XCDs' L2s
-# VALU issue ceiling: 256 CUs x 4 SIMDs x 16 lanes, one lane-operation per lane and cycle at 2.4 GHz
-N_SIMD, SIMD_LANES, CLOCK_HZ = 1024, 16, 2.4e9
+# VALU ceiling: 256 CUs x 4 SIMDs, each retiring a 64-lane full-rate instruction (v_fma_f32, v_add_f32,
+# v_mul_f32, 32-bit integer add / and / xor, v_mov_b32) every 2 cycles = 32 lanes per cycle, at the 2.4 GHz
+# peak clock. Measured on the card in shader cycles (tools/ubench/valu_rates.hip, profiles/r03_valu_rates.txt:
+# 2.25 - 2.3 cycles per wave64 v_fma_f32 from two waves per SIMD on, whatever the EXEC mask; 4.1 - 4.3 for
+# compares, selects, conversions, min / max, shifts, all FP64 arithmetic and v_pk_fma_f32; 8 for v_rcp_f32;
+# 16 for v_rcp_f64 / v_sqrt_f64; the loops ran at 2.0 - 2.4 GHz by s_memtime against s_memrealtime).
+N_SIMD, SIMD_LANES, CLOCK_HZ = 1024, 32, 2.4e9
+FULL_RATE_CYCLES = 2.0  # cycles a full-rate wave64 instruction occupies its SIMD
 LANE_OPS_PEAK_T = N_SIMD * SIMD_LANES * CLOCK_HZ / 1e12
 
 
@@ -70,6 +81,9 @@ def parse_args():
                     "round: dealt again after every adaptive round, one all-gather per round")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL; the real thing) or gloo (rehearsal of the "
                     "multi-rank flow with several ranks on one GPU, rows staged through the host)")
+    ap.add_argument("--sync-below", type=int, default=-1,
+                    help="active-pixel bounds at or below this are read back before the next round is queued "
+                         "(-1: render_frame's default)")
     ap.add_argument("--pixel-stride", type=int, default=1,
                     help="rehearsal: render every K-th pixel only, i.e. the work of one rank of K")
     return ap.parse_args()
@@ -161,6 +175,9 @@ def host_description():
     return {"cpu_model": model, "logical_cpus": os.cpu_count(), "cpus_usable_by_this_process": usable}
 
 
+# keys of a summary's `isa_mix` (tools/isa_mix.py: substrings of the mangled kernel names)
+MIX_NAMES = {"extend": "k_extendILb0", "shadow": "k_shadowILb0ELb0", "shade": "k_shadeILb0", "resolve": "k_resolve",
+             "trace2": "k_trace2ILb0ELb0", "light": "k_light"}
 KERNEL_NAMES = {"extend": "k_extend<false>", "shadow": "k_shadow<false, false>", "shade": "k_shade<false>",
                 "resolve": "k_resolve", "trace2": "k_trace2<false, false>"}
 
@@ -181,7 +198,14 @@ def profiled_counters(scene, kernel):
         k = KERNEL_NAMES[kernel]
         sq, sq2, grbm, l1 = d["pmc_sq"][k], d["pmc_sq2"][k], d["pmc_grbm"][k], d["pmc_l1"][k]
         n = sq2["_dispatches"]
-        return {"source": os.path.relpath(path, ROOT), "launches": n,
+        mix = (d.get("isa_mix") or {}).get(MIX_NAMES.get(kernel, ""), {})
+        try:
+            from summarize_prof import device_source_hash
+            stale = d.get("source_sha256") != device_source_hash(ROOT)
+        except Exception:
+            stale = None
+        return {"source": os.path.relpath(path, ROOT), "launches": n, "stale": stale,
+                "mean_cycles_per_inst": mix.get("mean_cycles"),
                 "lane_ops_per_launch": sq2["SQ_THREAD_CYCLES_VALU"] / n,
                 "valu_insts_per_launch": sq["SQ_INSTS_VALU"] / sq["_dispatches"],
                 "valu_issue_cycles_per_launch": 4.0 * sq["SQ_ACTIVE_INST_VALU"] / sq["_dispatches"],
@@ -265,7 +289,8 @@ def main():
                              ns_area_light=args.light_samples, seed=seed, specular=args.specular)
         hdr, cnt = distributed.render_frame(dev, p, rank=rank, world=world, device=device,
                                             pixel_stride=args.pixel_stride, target_paths=args.target_paths,
-                                            max_batches=args.max_batches, per_pixel=per_pixel, exchange=args.exchange)
+                                            max_batches=args.max_batches, per_pixel=per_pixel, exchange=args.exchange,
+                                            sync_below=None if args.sync_below < 0 else args.sync_below)
         return cnt
 
     # Warm-up frames time every kernel class with HIP events and so find the dominant one; the timed
@@ -411,18 +436,29 @@ def main():
                          "frac": ach / LANE_OPS_PEAK_T})
             roof["issue"] = {
                 "definition": "VALU lane-operations (SQ_THREAD_CYCLES_VALU) per launch / live time per launch, against "
-                              "%d SIMDs x %d lanes x %.1f GHz" % (N_SIMD, SIMD_LANES, CLOCK_HZ / 1e9),
+                              "%d SIMDs x %d lanes x %.1f GHz (full-rate wave64 instruction every %g cycles, measured: "
+                              "profiles/r03_valu_rates.txt)" % (N_SIMD, SIMD_LANES, CLOCK_HZ / 1e9, FULL_RATE_CYCLES),
                 "lane_ops_per_launch": pc["lane_ops_per_launch"],
                 "lane_ops_per_ray": pc["lane_ops_per_launch"] / max(roof.get("rays_per_launch") or 1, 1),
                 "valu_insts_per_ray": 64.0 * pc["valu_insts_per_launch"] / max(roof.get("rays_per_launch") or 1, 1),
-                # SQ_ACTIVE_INST_VALU x 4 over the cycles of all SIMDs during the profiled launch (a wave64
-                # instruction with every lane on occupies its SIMD for 4 cycles; the traversal kernels measure
-                # above 1 here with under half of their lanes on, so partly masked instructions cost less and
-                # this ratio is a diagnostic, not a bounded fraction - the lane-operation rate above is), and
-                # of the 64 lanes of those instructions the share that was active
-                "valu_insts_x4_per_simd_cycle": pc["valu_issue_cycles_per_launch"] / (pc["gpu_cycles_per_launch"] * N_SIMD),
+                # VALU instructions per SIMD cycle of the profiled launch (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs),
+                # and of the 64 lanes of those instructions the share that was switched on
+                "valu_insts_per_simd_cycle": pc["valu_insts_per_launch"] / (pc["gpu_cycles_per_launch"] * N_SIMD),
                 "lanes_active": pc["lane_ops_per_launch"] / (64.0 * pc["valu_insts_per_launch"]),
                 "profiled_avg_launch_ms": pc["trace_avg_launch_ms"], "source": pc["source"]}
+            if pc.get("mean_cycles_per_inst"):
+                # the kernel's instructions weighted by the cycles their issue class takes (static mix of the
+                # compiled kernel, tools/isa_mix.py): the share of SIMD cycles the VALU was busy, and the share
+                # of the full-rate peak this mix could reach with the VALU always busy and every lane on.
+                # frac = valu_busy x mix_allows x lanes_active x (profiled clock / 2.4 GHz)
+                mc = pc["mean_cycles_per_inst"]
+                roof["issue"]["mean_cycles_per_valu_inst"] = mc
+                roof["issue"]["valu_busy"] = roof["issue"]["valu_insts_per_simd_cycle"] * mc
+                roof["issue"]["mix_allows"] = FULL_RATE_CYCLES / mc
+            roof["issue"]["profiled_clock_ghz"] = pc["gpu_cycles_per_launch"] / (pc["trace_avg_launch_ms"] * 1e-3) / 1e9
+            if pc.get("stale") is not None:
+                # the counters were collected from other device sources than the ones this run was built from
+                roof["profile_stale"] = bool(pc["stale"])
             if "scaled_by_rays" in pc:
                 roof["issue"]["profile_scaled_by_rays_per_launch"] = pc["scaled_by_rays"]
             roof["l2_measured"] = {"read_requests_per_launch": pc["l2_read_requests_per_launch"], "hit_rate": pc["l2_hit"],

@@ -147,6 +147,7 @@ typedef struct ptamd_stats {
 #define PTAMD_K_FILTER 6
 #define PTAMD_K_OTHER 7
 #define PTAMD_K_TRACE2 8 /* one launch: bounce rays of depth d + 1 and shadow rays of depth d */
+#define PTAMD_K_LIGHT 9  /* light samples of the shaded vertices, one lane per sample */
 #define PTAMD_K_CLASSES 12
 
 typedef struct ptamd_scene ptamd_scene;     /* host scene (parsed + built) */

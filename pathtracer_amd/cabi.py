@@ -7,8 +7,9 @@ PRIM_TRIANGLE, PRIM_SPHERE = 0, 1
 MAT_DIFFUSE, MAT_EMISSION, MAT_MIRROR, MAT_MICROFACET, MAT_REFRACTION, MAT_GLASS = range(6)
 LIGHT_DIRECTIONAL, LIGHT_INF_HEMISPHERE, LIGHT_POINT, LIGHT_SPOT, LIGHT_AREA = range(5)
 K_NAMES = ("generate", "extend", "shade", "shadow", "resolve", "accumulate", "filter", "other", "trace2",
-           "class9", "class10", "class11")
+           "light", "class10", "class11")
 K_TRACE2 = 8
+K_LIGHT = 9
 
 _pi32 = C.POINTER(C.c_int32)
 _pf64 = C.POINTER(C.c_double)

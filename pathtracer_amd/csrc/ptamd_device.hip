@@ -199,6 +199,11 @@ struct VertexBuf {
   int32_t *self_code;  // [cap]
   float *self_dmin;    // [cap]
   int32_t *pend_prim;  // [cap * nls] primitive a shadow ray could not decide in FP32 (vis = 3), for k_resolve
+  // What k_light needs of a vertex that takes light samples (written by k_shade): the z axis of its
+  // shading frame (make_coord_space: n / |n|), and one 16-byte word: the Philox counter / key words
+  // (sample index, pixel) of its path and its material (f is recomputed from it: three multiplications).
+  double *nz[3];  // [cap]
+  uint4 *nee;     // [cap] {sample, pixel, material, -}
 };
 struct PathBuf {
   double *rad[3];
@@ -1417,7 +1422,7 @@ __global__ void __launch_bounds__(256)
     m3 o2w, w2o;
     o2w.c[0] = o2w.c[1] = o2w.c[2] = V(0, 0, 0);
     w2o = o2w;
-    int32_t path = 0, via = 0;
+    int32_t path = 0, via = 0, nee_mat = 0;
     uint32_t rng_s = 0, rng_pix = 0, rng_base = 0, n_emit = 0;
     if (valid) {
       const uint32_t j = list ? (uint32_t)list[i] : i;
@@ -1436,6 +1441,7 @@ __global__ void __launch_bounds__(256)
       } else {
         const int32_t info = S.prim_info[prim];
         const int32_t mat = info >> 1;
+        nee_mat = mat;
         const int32_t kind = S.mat_kind[mat];
         const v3 ro = V(q.o[0][j], q.o[1][j], q.o[2][j]);
         const v3 rd = V(q.d[0][j], q.d[1][j], q.d[2][j]);
@@ -1548,50 +1554,18 @@ __global__ void __launch_bounds__(256)
       qn.d[0][i] = next_d.x; qn.d[1][i] = next_d.y; qn.d[2][i] = next_d.z;
       qn.T[0][i] = next_T.x; qn.T[1][i] = next_T.y; qn.T[2][i] = next_T.z;
     }
-    // ---- light samples into their slots (estimate_direct_lighting_*, pathtracer.cpp:47-135)
-    VisWriter vis{vb.vis, (nls & 3) == 0, 0u};
-    if (do_nee) {
-      int qq = 0;
-      if (!HEMI) {
-        for (int li = 0; li < S.n_lights; li++) {
-          const int nsamp = light_is_delta(S.light_kind[li]) ? 1 : fp.ns_area_light;
-          for (int jj = 0; jj < nsamp; jj++, qq++) {
-            uint32_t wd[4];
-            philox4x32_10(rng_s, rng_base + 1u + (uint32_t)(qq >> 1), fp.seed_hi, 0u, fp.seed_lo, rng_pix, wd);
-            const double sx = u01(wd[2 * (qq & 1)]), sy = u01(wd[2 * (qq & 1) + 1]);
-            double pdf, dist;
-            v3 wi;
-            const v3 radiance = light_sample_L(S, li, hit_p, sx, sy, wi, dist, pdf);
-            const v3 wi_o = mmul(w2o, wi);
-            const size_t slot = (size_t)i * nls + qq;
-            bool emit = !(wi_o.z < 0 || (radiance.x == 0 && radiance.y == 0 && radiance.z == 0));
-            // The primitives at the far end of this light's shadow rays are tested here, by the reference's
-            // test and its rule (bvh.cpp:187: a hit strictly before the ray's end occludes), with every
-            // lane busy; a ray they occlude is never traced, and the walk of the others skips them.
-            // (Measured and rejected: the walk's FP32 pre-test in front of each of these tests, which
-            // settles the triangle of the quad the sample point does not lie on: k_shade 9 % slower.)
-            if (emit && S.has_end && S.light_tag[li]) {
-#pragma unroll 1
-              for (int k = 0; k < 4; k++) {
-                const int32_t ep = S.light_end[4 * li + k];
-                if (ep < 0) break;
-                double te, ue, ve;
-                if (exact_test(S, ep, hit_p, wi, PT_EPS_D, te, ue, ve) && te < dist) { emit = false; break; }
-              }
-            }
-            if (emit) {
-              const v3 term = vdivs(vscale(vmul(f, radiance), fabs(wi_o.z)), pdf);
-              sq.ray[slot] = SRay{{wi.x, wi.y, wi.z}, dist};
-              vb.contrib[slot] = Contrib{{term.x, term.y, term.z}};
-              vis.put(slot, 2);
-              n_emit++;
-            } else {
-              vis.put(slot, 0);
-            }
-          }
-        }
-      } else {
-        for (qq = 0; qq < nls; qq++) {
+    // ---- light samples (estimate_direct_lighting_*, pathtracer.cpp:47-135). Importance sampling of the
+    // lights runs one lane per SAMPLE in the next launch, k_light: this kernel leaves it what it needs of
+    // the vertex. Hemisphere sampling (-H) draws its samples here.
+    if (!HEMI) {
+      if (do_nee) {
+        vb.nz[0][i] = o2w.c[2].x; vb.nz[1][i] = o2w.c[2].y; vb.nz[2][i] = o2w.c[2].z;
+        vb.nee[i] = make_uint4(rng_s, rng_pix, (uint32_t)nee_mat, 0u);
+      }
+    } else {
+      VisWriter vis{vb.vis, (nls & 3) == 0, 0u};
+      if (do_nee) {
+        for (int qq = 0; qq < nls; qq++) {
           uint32_t wd[4];
           philox4x32_10(rng_s, rng_base + 1u + (uint32_t)(qq >> 1), fp.seed_hi, 0u, fp.seed_lo, rng_pix, wd);
           const v3 wi = uniform_hemisphere_sample(u01(wd[2 * (qq & 1)]), u01(wd[2 * (qq & 1) + 1]));
@@ -1603,9 +1577,9 @@ __global__ void __launch_bounds__(256)
           vis.put(slot, 2);
           n_emit++;
         }
+      } else if (valid && nls > 0) {
+        for (int qq = 0; qq < nls; qq++) vis.put((size_t)i * nls + qq, 0);
       }
-    } else if (valid && nls > 0) {
-      for (int qq = 0; qq < nls; qq++) vis.put((size_t)i * nls + qq, 0);
     }
     // ---- per-block counts for the compaction: wave64 ballot / reduction, then LDS
     const unsigned long long pm = __ballot(push);
@@ -1616,9 +1590,88 @@ __global__ void __launch_bounds__(256)
     if (threadIdx.x == 0) {
       const uint32_t vbk = base_i >> 8;
       cp.cnt_next[vbk] = wsum[0][0] + wsum[0][1] + wsum[0][2] + wsum[0][3];
+      // (importance sampling: zero here, k_light's workgroups add their shadow rays)
       cp.cnt_shadow[vbk] = wsum[1][0] + wsum[1][1] + wsum[1][2] + wsum[1][3];
     }
     __syncthreads();
+  }
+}
+
+// The light samples of the vertices k_shade has just shaded, one lane per SAMPLE: slot = entry * nls + q
+// (estimate_direct_lighting_importance, pathtracer.cpp:93-135; the sample's light and its index within
+// that light follow from q as the reference's two loops enumerate them). A vertex's samples sit in
+// adjacent lanes, so what they share (hit point, frame axis, f, counter words) is one fetch per
+// wave and the 32- and 24-byte records of a wave's 64 slots are contiguous. Per sample: a Philox
+// block, sample_L, the cosine against the frame's z axis (w2o * wi needs only that row), the
+// reference's test of the primitives at the light's far end, the shadow-ray and contribution
+// records, the visibility byte; per workgroup the number of shadow rays, added to the count of its
+// 256-entry block for the compaction (an integer sum: the same on every run).
+// Split off k_shade, where one lane ran the whole light loop of its vertex at 131 registers.
+__global__ void __launch_bounds__(256)
+    k_light(FrameParams fp, DevScene S, VertexBuf vb, ShadowQ sq, Compact cp, Ctl *ctl, FastDiv by_nls, uint32_t rng_base) {
+  __shared__ uint32_t wsum[4];
+  const uint32_t n = ctl->n_cur;
+  const uint32_t nls = (uint32_t)fp.nls;
+  const uint32_t n_slots = n * nls;  // < 2^31 (ptamd_trace_list)
+  const uint32_t slot0 = blockIdx.x * 256u;
+  if (slot0 >= n_slots) return;
+  const uint32_t slot = slot0 + threadIdx.x;
+  bool emit = false;
+  if (slot < n_slots) {
+    const uint32_t i = by_nls.div(slot);
+    uint32_t q = slot - i * nls;
+    if (vb.flag[i] & 1) {
+      const uint32_t qq = q;
+      int li = 0;
+      for (; li < S.n_lights - 1; li++) {
+        const uint32_t nsamp = light_is_delta(S.light_kind[li]) ? 1u : (uint32_t)fp.ns_area_light;
+        if (q < nsamp) break;
+        q -= nsamp;
+      }
+      const uint4 rk = vb.nee[i];
+      const v3 hit_p = V(vb.hp[0][i], vb.hp[1][i], vb.hp[2][i]);
+      const v3 z = V(vb.nz[0][i], vb.nz[1][i], vb.nz[2][i]);
+      uint32_t wd[4];
+      philox4x32_10(rk.x, rng_base + 1u + (qq >> 1), fp.seed_hi, 0u, fp.seed_lo, rk.y, wd);
+      const double sx = u01(wd[2 * (qq & 1)]), sy = u01(wd[2 * (qq & 1) + 1]);
+      double pdf, dist;
+      v3 wi;
+      const v3 radiance = light_sample_L(S, li, hit_p, sx, sy, wi, dist, pdf);
+      // (w2o * wi).z: the row of w2o that is the frame's z axis, summed as mmul sums it
+      const double wi_o_z = z.x * wi.x + z.y * wi.y + z.z * wi.z;
+      emit = !(wi_o_z < 0 || (radiance.x == 0 && radiance.y == 0 && radiance.z == 0));
+      // The primitives at the far end of this light's shadow rays are tested here, by the reference's
+      // test and its rule (bvh.cpp:187: a hit strictly before the ray's end occludes); a ray they
+      // occlude is never traced, and the walk of the others skips them.
+      // (Measured and rejected: the walk's FP32 pre-test in front of each of these tests, which
+      // settles the triangle of the quad the sample point does not lie on: 9 % slower.)
+      if (emit && S.has_end && S.light_tag[li]) {
+#pragma unroll 1
+        for (int k = 0; k < 4; k++) {
+          const int32_t ep = S.light_end[4 * li + k];
+          if (ep < 0) break;
+          double te, ue, ve;
+          if (exact_test(S, ep, hit_p, wi, PT_EPS_D, te, ue, ve) && te < dist) { emit = false; break; }
+        }
+      }
+      if (emit) {
+        // DiffuseBSDF::f, bsdf.cpp:52-58 (only Lambertian vertices take light samples)
+        const double *rho = S.mat_param + 3 * (size_t)rk.z;
+        const v3 f = vdivs(V(rho[0], rho[1], rho[2]), PT_PI);
+        const v3 term = vdivs(vscale(vmul(f, radiance), fabs(wi_o_z)), pdf);
+        sq.ray[slot] = SRay{{wi.x, wi.y, wi.z}, dist};
+        vb.contrib[slot] = Contrib{{term.x, term.y, term.z}};
+      }
+    }
+    vb.vis[slot] = emit ? 2 : 0;
+  }
+  const unsigned long long m = __ballot(emit);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = (uint32_t)__popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t t = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    // 256 consecutive slots from a multiple of 256 lie inside one block of 256 entries x nls slots
+    if (t) atomicAdd(&cp.cnt_shadow[blockIdx.x / nls], t);
   }
 }
 
@@ -2164,7 +2217,7 @@ int ensure_buffers(ptamd_context *c, int64_t paths, int nls, bool pend) {
   auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
   size_t total = 0;
   auto take = [&](size_t bytes) { size_t o = total; total += al(bytes); return o; };
-  size_t off_q[2][10], off_hit[4], off_sq[5], off_vb[8], off_pb[6], off_list[2], off_cp[3];
+  size_t off_q[2][10], off_hit[4], off_sq[5], off_vb[8], off_pb[6], off_list[2], off_cp[3], off_nee[4];
   for (int k = 0; k < 2; k++) {
     off_q[k][0] = take(P * 4);
     for (int j = 1; j < 10; j++) off_q[k][j] = take(P * 8);
@@ -2179,6 +2232,8 @@ int ensure_buffers(ptamd_context *c, int64_t paths, int nls, bool pend) {
   off_vb[4] = take(PN * sizeof(Contrib));
   off_vb[7] = take(PN + 4);
   off_vb[5] = take(PN * 4);
+  for (int j = 0; j < 3; j++) off_nee[j] = take(P * 8);
+  off_nee[3] = take(P * 16);
   for (int j = 0; j < 6; j++) off_pb[j] = take(P * 8);
   for (int k = 0; k < 2; k++) off_list[k] = take(P * 4);
   off_cp[0] = take(P);
@@ -2205,6 +2260,8 @@ int ensure_buffers(ptamd_context *c, int64_t paths, int nls, bool pend) {
   c->vb.flag = (uint8_t *)(b + off_vb[3]);
   c->vb.contrib = (Contrib *)(b + off_vb[4]);
   c->vb.vis = (uint8_t *)(b + off_vb[7]);
+  for (int j = 0; j < 3; j++) c->vb.nz[j] = (double *)(b + off_nee[j]);
+  c->vb.nee = (uint4 *)(b + off_nee[3]);
   for (int j = 0; j < 3; j++) {
     c->pb.rad[j] = (double *)(b + off_pb[j]);
     c->pb.pend[j] = (double *)(b + off_pb[3 + j]);
@@ -2826,6 +2883,7 @@ int ptamd_trace_list(ptamd_context *c, const ptamd_pixel_list *list, int32_t sam
   const int ggrid = grid_for(c, 8);
   // k_shade runs one workgroup per 256 list entries; no list of this call is longer than a chunk's paths
   const int shade_grid = (int)((px_per_chunk * n_samples + 255) / 256);
+  const int light_grid = (int)(((int64_t)shade_grid * 256 * nls + 255) / 256);  // k_light: one workgroup per 256 light-sample slots
   PathBuf pb = c->pb;
   if (fp.accum) pb.pend[0] = pb.pend[1] = pb.pend[2] = nullptr;
   const PixView pv = view_of(list);
@@ -2864,6 +2922,12 @@ int ptamd_trace_list(ptamd_context *c, const ptamd_pixel_list *list, int32_t sam
         hipLaunchKernelGGL(k_shade<false>, shade_grid, 256, 0, s, fp, c->S, c->q[cur], lst, c->hb, c->q[cur ^ 1], c->sq, vb, pb,
                            c->cp, c->ctl, depth, pv, up0, rp);
       L.end();
+      if (!fp.hemisphere && fp.max_ray_depth > 0 && fp.nls > 0) {
+        L.begin(PTAMD_K_LIGHT);
+        hipLaunchKernelGGL(k_light, light_grid, 256, 0, s, fp, c->S, vb, c->sq, c->cp, c->ctl, by_nls,
+                           1u + (uint32_t)(depth - 1) * (uint32_t)fp.bpv);
+        L.end();
+      }
       L.begin(PTAMD_K_OTHER);
       hipLaunchKernelGGL(k_scan2, 1, 1024, 0, s, c->cp, c->ctl);
       hipLaunchKernelGGL(k_scatter, ggrid, 256, 0, s, c->cp, vb, c->list[cur ^ 1], c->sq, c->ctl, fp.max_ray_depth > 0 ? fp.nls : 0);

@@ -77,6 +77,52 @@ def per_pixel_default(params):
     return params.ns_aa >= 16 * max(1, params.samples_per_batch)
 
 
+# Pixel index lists by (frame geometry, stride, offset, device): building one takes half a dozen
+# small launches and as many host round trips, 0.7 ms in front of a frame that a rank of 8 renders
+# in 25 ms. Callers must not write to the lists.
+_pixel_lists = {}
+
+
+def _frame_pixels(w, x0, y0, x1, y1, offset, stride, device):
+    key = (w, x0, y0, x1, y1, offset, stride, str(device))
+    got = _pixel_lists.get(key)
+    if got is None:
+        ys = torch.arange(y0, y1, device=device, dtype=torch.int32)
+        xs = torch.arange(x0, x1, device=device, dtype=torch.int32)
+        got = (ys[:, None] * w + xs[None, :]).reshape(-1)[offset::max(1, stride)].contiguous()
+        if len(_pixel_lists) >= 16:
+            _pixel_lists.clear()
+        _pixel_lists[key] = got
+    return got
+
+
+class _CountReader:
+    """List lengths on their way back to the host: a small ring of pinned words and events, reused."""
+
+    def __init__(self, device, slots=4):
+        self.on_gpu = device.type == "cuda"
+        self.host = torch.empty(slots, dtype=torch.int64, pin_memory=self.on_gpu)
+        self.events = [torch.cuda.Event() for _ in range(slots)] if self.on_gpu else [None] * slots
+        self.device, self.k, self.slots = device, 0, slots
+
+    def post(self, src):
+        """Queues the copy of the one-element tensor `src`; returns a ticket for read()."""
+        k = self.k
+        self.k = (k + 1) % self.slots
+        self.host[k:k + 1].copy_(src, non_blocking=True)
+        if self.on_gpu:
+            self.events[k].record(torch.cuda.current_stream(self.device))
+        return k
+
+    def read(self, k):
+        if self.on_gpu:
+            self.events[k].synchronize()
+        return int(self.host[k].item())
+
+
+_count_readers = {}
+
+
 def _all_gather_rows(dist, recv, send, group, on_gpu):
     if on_gpu and dist.get_backend(group) == "gloo":
         # rehearsal without RCCL (several ranks sharing one GPU): stage through the host
@@ -131,26 +177,29 @@ def render_frame(dev, params, rank=0, world=1, group=None, device=None, record_r
     state = torch.zeros(npix * 6, dtype=torch.float64, device=device)
     x0, y0 = max(0, params.x0), max(0, params.y0)
     x1, y1 = min(w, params.x1), min(h, params.y1)
-    ys = torch.arange(y0, y1, device=device, dtype=torch.int32)
-    xs = torch.arange(x0, x1, device=device, dtype=torch.int32)
     if per_pixel is None:
         per_pixel = per_pixel_default(params)
     if exchange not in ("frame", "round"):
         raise ValueError("exchange must be 'frame' or 'round'")
-    all_pix = (ys[:, None] * w + xs[None, :]).reshape(-1)[pixel_offset::max(1, pixel_stride)].contiguous()
+    all_pix = _frame_pixels(w, x0, y0, x1, y1, pixel_offset, pixel_stride, device)
     n_all = all_pix.numel()
+    rkey = (str(device), stream)  # one ring per stream: frames on different streams may run from different threads
+    reader = _count_readers.get(rkey)
+    if reader is None or reader.slots < lag + 2:
+        reader = _count_readers[rkey] = _CountReader(device, slots=max(4, lag + 2))
     deal_once = world > 1 and exchange == "frame"
     if deal_once:
         # this rank's pixels for the whole frame; the loop below then runs as a single rank would
         frame_rank, frame_world = rank, world
-        bufs = [all_pix[rank::world].contiguous(), None]
+        first = _frame_pixels(w, x0, y0, x1, y1, pixel_offset + rank * max(1, pixel_stride), world * max(1, pixel_stride), device)
         rank, world = 0, 1
     else:
-        bufs = [all_pix, None]
-    bufs[1] = torch.empty_like(bufs[0])
-    n0 = bufs[0].numel()
-    n_dev = torch.full((2,), n0, dtype=torch.int64, device=device)  # lengths of bufs[0], bufs[1]
-    pending = []  # (event or None, host tensor) of counts not yet read
+        first = all_pix
+    # bufs[0] is the cached, read-only list of the frame's pixels; the survivor lists alternate between the other two
+    bufs = [first, torch.empty_like(first), torch.empty_like(first)]
+    n0 = first.numel()
+    n_dev = torch.full((3,), n0, dtype=torch.int64, device=device)  # lengths of the three lists
+    pending = []  # tickets of counts not yet read
     rows_send = rows_recv = None
     if world > 1:
         m0 = PixelSchedule.padded(n0, world)
@@ -168,23 +217,15 @@ def render_frame(dev, params, rank=0, world=1, group=None, device=None, record_r
             # the adaptive test of raytrace_pixel at i = done (per_pixel: at each pixel's own
             # count); every rank holds the whole state, so every rank computes the same survivor list
             whole = cabi.PixelList(bufs[cur].data_ptr(), n_dev[cur:].data_ptr(), 0, bound, 0, 1)
-            dev.filter_list(whole, -1 if per_pixel else done, state.data_ptr(), bufs[cur ^ 1].data_ptr(),
-                            n_dev[cur ^ 1:].data_ptr(), stream)
-            cur ^= 1
-            host_n = torch.empty(1, dtype=torch.int64, pin_memory=on_gpu)
-            host_n.copy_(n_dev[cur:cur + 1], non_blocking=True)
-            ev = None
-            if on_gpu:
-                ev = torch.cuda.Event()
-                ev.record(torch.cuda.current_stream(device))
-            pending.append((ev, host_n))
+            nxt = 2 if cur == 1 else 1
+            dev.filter_list(whole, -1 if per_pixel else done, state.data_ptr(), bufs[nxt].data_ptr(),
+                            n_dev[nxt:].data_ptr(), stream)
+            cur = nxt
+            pending.append(reader.post(n_dev[cur:cur + 1]))
             # (a short list is read back at once: waiting for its count idles the GPU for tens of
             # microseconds, queueing a round for pixels that have all stopped costs a round of launches)
             while len(pending) > (lag if bound > sync_below else 0):
-                ev, t = pending.pop(0)
-                if ev is not None:
-                    ev.synchronize()
-                bound = min(bound, int(t.item()))
+                bound = min(bound, reader.read(pending.pop(0)))
             if bound == 0:
                 break
         ns = batch * PixelSchedule.batches(bound, world, batch, params.ns_aa - done, target_paths, max_batches,

@@ -5,6 +5,7 @@
 set -e
 OUT=$1; shift
 tools/pmc_passes.sh "$OUT" "$@"
+python3 tools/isa_mix.py --json "$OUT/isa_mix.json" > "$OUT/isa_mix.txt"
 python3 tools/summarize_prof.py "$OUT" > "$OUT/summary.txt"
 python3 tools/trace_hist.py "$OUT/trace" > "$OUT/duration_hist.txt"
 find "$OUT/trace" -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats.csv" \;

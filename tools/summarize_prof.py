@@ -34,9 +34,28 @@ def counters(d, name):
     return {k: dict(v, _dispatches=max(n[(k, c)] for c in v)) for k, v in acc.items()}
 
 
+def device_source_hash(root=None):
+    """SHA-256 over the device layer's sources (pathtracer_amd/csrc/*.hip and *.h, by name): a counter
+    summary is only valid for the kernels it was collected from, and bench.py compares this with the
+    tree it runs in."""
+    import hashlib
+    root = root or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(root, "pathtracer_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(src)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(src, f), "rb").read())
+    return h.hexdigest()
+
+
 def main():
     d = sys.argv[1]
-    res = {"kernels": kernel_stats(d)}
+    res = {"kernels": kernel_stats(d), "source_sha256": device_source_hash()}
+    try:  # static VALU instruction mix by issue class (tools/isa_mix.py --json <outdir>/isa_mix.json)
+        res["isa_mix"] = json.load(open(os.path.join(d, "isa_mix.json")))
+    except Exception:
+        pass
     for p in ("pmc_fetch", "pmc_write", "pmc_l2", "pmc_sq", "pmc_grbm", "pmc_sq2", "pmc_l1"):
         res[p] = counters(d, p)
     try:

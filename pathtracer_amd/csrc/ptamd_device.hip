@@ -405,10 +405,26 @@ __device__ __forceinline__ void cswap(float &ta, int32_t &ca, float &tb, int32_t
 // first root that is not below min_t: the reference takes the first root inside
 // [min_t, max_t], and when the first root at or beyond min_t lies beyond max_t so does the
 // second, so comparing this t with max_t decides as the reference does.
-__device__ __forceinline__ bool exact_test(const DevScene &S, int p, const v3 &o, const v3 &d, double min_t, double &t,
-                                           double &u, double &v) {
-  const double *P = S.prim + (size_t)p * PRIM_STRIDE;
-  const int32_t info = reinterpret_cast<const int32_t *>(P + 9)[0];
+// Read-only tables reached through wave-uniform addresses (the lights, the records of their end
+// primitives) are read through pointers in the constant address space: the compiler then fetches
+// them with scalar loads (one request per wave through the scalar cache, the values in scalar
+// registers) instead of one vector load per lane. Nothing is ever written through such a pointer;
+// the host fills these tables before any kernel runs.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PT_CONST_AS __attribute__((address_space(4)))
+#else
+#define PT_CONST_AS  // the host pass only parses the device code
+#endif
+template <class T>
+__device__ __forceinline__ const PT_CONST_AS T *uniform_table(const T *p) {
+  return (const PT_CONST_AS T *)p;
+}
+__device__ __forceinline__ int32_t low_word(double x) { return __double2loint(x); }
+
+// P: the primitive's FP64 record (PRIM_STRIDE doubles), through either kind of pointer
+template <class Rec>
+__device__ __forceinline__ bool exact_test_rec(Rec P, const v3 &o, const v3 &d, double min_t, double &t, double &u, double &v) {
+  const int32_t info = low_word(P[9]);
   t = 0; u = 0; v = 0;
   if (!(info & 1)) {
     const v3 p1 = V(P[0], P[1], P[2]), e1 = V(P[3], P[4], P[5]), e2 = V(P[6], P[7], P[8]);
@@ -433,6 +449,10 @@ __device__ __forceinline__ bool exact_test(const DevScene &S, int p, const v3 &o
   if (t1 >= min_t) { t = t1; return true; }
   if (t2 >= min_t) { t = t2; return true; }
   return false;
+}
+__device__ __forceinline__ bool exact_test(const DevScene &S, int p, const v3 &o, const v3 &d, double min_t, double &t,
+                                           double &u, double &v) {
+  return exact_test_rec(S.prim + (size_t)p * PRIM_STRIDE, o, d, min_t, t, u, v);
 }
 
 // State of one ray's walk.
@@ -599,6 +619,8 @@ struct Walk {
       cur_t = a0 ? t[0] : (a1 ? t[1] : (a2 ? t[2] : t[3]));
       return;
     }
+    // (Measured and rejected: finding only the nearest child, 3 or 4 compare-and-swaps instead of the 5 of a
+    // full sort, and pushing the others in slot order: the frame 0.1 to 0.9 % slower, k_extend 17 % slower.)
     cswap(t[0], c[0], t[1], c[1]);
     cswap(t[2], c[2], t[3], c[3]);
     cswap(t[0], c[0], t[2], c[2]);
@@ -1002,11 +1024,11 @@ __device__ __forceinline__ bool light_is_delta(int kind) {  // src/scene/light.h
   return kind == PTAMD_LIGHT_DIRECTIONAL || kind == PTAMD_LIGHT_POINT || kind == PTAMD_LIGHT_SPOT;
 }
 // SceneLight::sample_L for every light kind, src/scene/light.cpp:17-93
-__device__ __forceinline__ v3 light_sample_L(const DevScene &S, int li, v3 p, double sx, double sy, v3 &wi,
-                                             double &dist, double &pdf) {
-  const double *q = S.light_param + 16 * li;
+// kind, q: the light's kind and its 16 parameters (through either kind of pointer)
+template <class Rec>
+__device__ __forceinline__ v3 light_sample_rec(int kind, Rec q, v3 p, double sx, double sy, v3 &wi, double &dist, double &pdf) {
   const v3 radiance = V(q[0], q[1], q[2]);
-  switch (S.light_kind[li]) {
+  switch (kind) {
     case PTAMD_LIGHT_AREA: {
       const v3 position = V(q[3], q[4], q[5]), direction = V(q[6], q[7], q[8]);
       const v3 dim_x = V(q[9], q[10], q[11]), dim_y = V(q[12], q[13], q[14]);
@@ -1607,71 +1629,115 @@ __global__ void __launch_bounds__(256)
 // records, the visibility byte; per workgroup the number of shadow rays, added to the count of its
 // 256-entry block for the compaction (an integer sum: the same on every run).
 // Split off k_shade, where one lane ran the whole light loop of its vertex at 131 registers.
-__global__ void __launch_bounds__(256)
+#ifndef PTAMD_LIGHT_LOOP
+#define PTAMD_LIGHT_LOOP 0  // workgroups per CU of a grid-stride k_light (0: one workgroup per 256 slots of the launch's upper bound)
+#endif
+#ifndef PTAMD_LIGHT_WAVES
+#define PTAMD_LIGHT_WAVES 0  // waves per SIMD k_light is compiled for (0: the compiler's choice)
+#endif
+#if PTAMD_LIGHT_WAVES
+#define LIGHT_BOUNDS __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PTAMD_LIGHT_WAVES, PTAMD_LIGHT_WAVES)))
+#else
+#define LIGHT_BOUNDS __launch_bounds__(256)
+#endif
+__global__ void LIGHT_BOUNDS
     k_light(FrameParams fp, DevScene S, VertexBuf vb, ShadowQ sq, Compact cp, Ctl *ctl, FastDiv by_nls, uint32_t rng_base) {
   __shared__ uint32_t wsum[4];
   const uint32_t n = ctl->n_cur;
   const uint32_t nls = (uint32_t)fp.nls;
   const uint32_t n_slots = n * nls;  // < 2^31 (ptamd_trace_list)
-  const uint32_t slot0 = blockIdx.x * 256u;
+#if PTAMD_LIGHT_LOOP
+  for (uint32_t blk = blockIdx.x; blk * 256u < n_slots; blk += gridDim.x) {
+#else
+  const uint32_t blk = blockIdx.x;
+  {
+#endif
+  const uint32_t slot0 = blk * 256u;
   if (slot0 >= n_slots) return;
   const uint32_t slot = slot0 + threadIdx.x;
+  const bool in = slot < n_slots;
+  // Everything a lane needs of its vertex is fetched at once, before the flag says whether it is
+  // needed (lanes past the end read the last slot's vertex): the kernel's time is the chain of its
+  // memory round trips, not its arithmetic. For the same reason all that depends on the LIGHT only
+  // (kind, parameters, end primitives and their records) is read through wave-uniform addresses,
+  // i.e. scalar loads: the loop below runs over the lights, each taking the lanes whose sample
+  // belongs to it, instead of each lane looking its light up.
+  const uint32_t i = by_nls.div(in ? slot : n_slots - 1u);
+  const uint32_t q = (in ? slot : n_slots - 1u) - i * nls;
+  const uint8_t flag = vb.flag[i];
+  const uint4 rk = vb.nee[i];
+  const v3 hit_p = V(vb.hp[0][i], vb.hp[1][i], vb.hp[2][i]);
+  const v3 z = V(vb.nz[0][i], vb.nz[1][i], vb.nz[2][i]);
+  const bool want = in && (flag & 1);
   bool emit = false;
-  if (slot < n_slots) {
-    const uint32_t i = by_nls.div(slot);
-    uint32_t q = slot - i * nls;
-    if (vb.flag[i] & 1) {
-      const uint32_t qq = q;
-      int li = 0;
-      for (; li < S.n_lights - 1; li++) {
-        const uint32_t nsamp = light_is_delta(S.light_kind[li]) ? 1u : (uint32_t)fp.ns_area_light;
-        if (q < nsamp) break;
-        q -= nsamp;
-      }
-      const uint4 rk = vb.nee[i];
-      const v3 hit_p = V(vb.hp[0][i], vb.hp[1][i], vb.hp[2][i]);
-      const v3 z = V(vb.nz[0][i], vb.nz[1][i], vb.nz[2][i]);
+  if (__ballot(want)) {
+    double sx = 0, sy = 0;
+    if (want) {
       uint32_t wd[4];
-      philox4x32_10(rk.x, rng_base + 1u + (qq >> 1), fp.seed_hi, 0u, fp.seed_lo, rk.y, wd);
-      const double sx = u01(wd[2 * (qq & 1)]), sy = u01(wd[2 * (qq & 1) + 1]);
-      double pdf, dist;
-      v3 wi;
-      const v3 radiance = light_sample_L(S, li, hit_p, sx, sy, wi, dist, pdf);
-      // (w2o * wi).z: the row of w2o that is the frame's z axis, summed as mmul sums it
-      const double wi_o_z = z.x * wi.x + z.y * wi.y + z.z * wi.z;
-      emit = !(wi_o_z < 0 || (radiance.x == 0 && radiance.y == 0 && radiance.z == 0));
+      philox4x32_10(rk.x, rng_base + 1u + (q >> 1), fp.seed_hi, 0u, fp.seed_lo, rk.y, wd);
+      sx = u01(wd[2 * (q & 1)]);
+      sy = u01(wd[2 * (q & 1) + 1]);
+    }
+    const auto *light_kind = uniform_table(S.light_kind);
+    const auto *light_param = uniform_table(S.light_param);
+    const auto *light_tag = uniform_table(S.light_tag);
+    const auto *light_end = uniform_table(S.light_end);
+    const auto *prim_rec = uniform_table(S.prim);
+    uint32_t base = 0;
+    for (int li = 0; li < S.n_lights; li++) {  // wave-uniform
+      const int kind = light_kind[li];
+      const uint32_t nsamp = light_is_delta(kind) ? 1u : (uint32_t)fp.ns_area_light;
+      const bool mine = want && q >= base && q < base + nsamp;
+      base += nsamp;
+      if (!__ballot(mine)) continue;
+      double pdf = 1, dist = 0, wi_o_z = 0;
+      v3 wi = V(0, 0, 0), radiance = V(0, 0, 0);
+      bool e = false;
+      if (mine) {
+        radiance = light_sample_rec(kind, light_param + 16 * li, hit_p, sx, sy, wi, dist, pdf);
+        // (w2o * wi).z: the row of w2o that is the frame's z axis, summed as mmul sums it
+        wi_o_z = z.x * wi.x + z.y * wi.y + z.z * wi.z;
+        e = !(wi_o_z < 0 || (radiance.x == 0 && radiance.y == 0 && radiance.z == 0));
+      }
       // The primitives at the far end of this light's shadow rays are tested here, by the reference's
       // test and its rule (bvh.cpp:187: a hit strictly before the ray's end occludes); a ray they
       // occlude is never traced, and the walk of the others skips them.
       // (Measured and rejected: the walk's FP32 pre-test in front of each of these tests, which
       // settles the triangle of the quad the sample point does not lie on: 9 % slower.)
-      if (emit && S.has_end && S.light_tag[li]) {
+      if (S.has_end && light_tag[li]) {
 #pragma unroll 1
         for (int k = 0; k < 4; k++) {
-          const int32_t ep = S.light_end[4 * li + k];
+          const int32_t ep = light_end[4 * li + k];  // wave-uniform, and so is its record
           if (ep < 0) break;
-          double te, ue, ve;
-          if (exact_test(S, ep, hit_p, wi, PT_EPS_D, te, ue, ve) && te < dist) { emit = false; break; }
+          if (e) {
+            double te, ue, ve;
+            if (exact_test_rec(prim_rec + (size_t)ep * PRIM_STRIDE, hit_p, wi, PT_EPS_D, te, ue, ve) && te < dist) e = false;
+          }
         }
       }
-      if (emit) {
+      if (e) {
         // DiffuseBSDF::f, bsdf.cpp:52-58 (only Lambertian vertices take light samples)
         const double *rho = S.mat_param + 3 * (size_t)rk.z;
         const v3 f = vdivs(V(rho[0], rho[1], rho[2]), PT_PI);
         const v3 term = vdivs(vscale(vmul(f, radiance), fabs(wi_o_z)), pdf);
         sq.ray[slot] = SRay{{wi.x, wi.y, wi.z}, dist};
         vb.contrib[slot] = Contrib{{term.x, term.y, term.z}};
+        emit = true;
       }
     }
-    vb.vis[slot] = emit ? 2 : 0;
   }
+  if (in) vb.vis[slot] = emit ? 2 : 0;
   const unsigned long long m = __ballot(emit);
   if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = (uint32_t)__popcll(m);
   __syncthreads();
   if (threadIdx.x == 0) {
     const uint32_t t = wsum[0] + wsum[1] + wsum[2] + wsum[3];
     // 256 consecutive slots from a multiple of 256 lie inside one block of 256 entries x nls slots
-    if (t) atomicAdd(&cp.cnt_shadow[blockIdx.x / nls], t);
+    if (t) atomicAdd(&cp.cnt_shadow[blk / nls], t);
+  }
+#if PTAMD_LIGHT_LOOP
+  __syncthreads();
+#endif
   }
 }
 
@@ -2924,7 +2990,7 @@ int ptamd_trace_list(ptamd_context *c, const ptamd_pixel_list *list, int32_t sam
       L.end();
       if (!fp.hemisphere && fp.max_ray_depth > 0 && fp.nls > 0) {
         L.begin(PTAMD_K_LIGHT);
-        hipLaunchKernelGGL(k_light, light_grid, 256, 0, s, fp, c->S, vb, c->sq, c->cp, c->ctl, by_nls,
+        hipLaunchKernelGGL(k_light, PTAMD_LIGHT_LOOP ? std::min(light_grid, grid_for(c, PTAMD_LIGHT_LOOP)) : light_grid, 256, 0, s, fp, c->S, vb, c->sq, c->cp, c->ctl, by_nls,
                            1u + (uint32_t)(depth - 1) * (uint32_t)fp.bpv);
         L.end();
       }

@@ -23,6 +23,6 @@ for f in glob.glob(os.path.join(sys.argv[1], "p*", "**", "*counter_collection.cs
         k = (m.group(1) + (m.group(2) or "")) if m else r["Kernel_Name"][:40]
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
 for k in sorted(acc):
-    if k.startswith(("k_extend", "k_shadow", "k_shade", "k_resolve")):
+    if k.startswith(("k_extend", "k_shadow", "k_shade", "k_resolve", "k_light", "k_trace2")):
         print(k, {c: "%.4g" % v for c, v in sorted(acc[k].items())})
 PY

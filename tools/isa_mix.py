@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Static VALU instruction mix of the device layer's kernels, by issue class.
 
-    python3 tools/isa_mix.py [--src pathtracer_amd/csrc/ptamd_device.hip] [--json out.json] [kernel substrings...]
+    python3 tools/isa_mix.py [--src unit.hip ...] [--json out.json] [kernel substrings...]
 
-Compiles the device source for gfx950 with --save-temps (in a scratch directory) and counts, per
+Compiles the device layer's kernel units for gfx950 with --save-temps (in a scratch directory) and counts, per
 kernel, the VALU instructions of its body by the issue class the cycle-stamped microbenchmark
 (tools/ubench/valu_rates.hip) found on MI355X at two or more waves per SIMD:
 
@@ -93,12 +93,15 @@ def mix(body):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--src", default=os.path.join(ROOT, "pathtracer_amd", "csrc", "ptamd_device.hip"))
-    ap.add_argument("--asm", default=None, help="an existing gfx950 .s file instead of compiling")
+    csrc = os.path.join(ROOT, "pathtracer_amd", "csrc")
+    ap.add_argument("--src", nargs="*", default=[os.path.join(csrc, u) for u in ("trace_kernels.hip", "shade_kernels.hip")])
+    ap.add_argument("--asm", nargs="*", default=None, help="existing gfx950 .s files instead of compiling")
     ap.add_argument("--json", default=None)
-    ap.add_argument("names", nargs="*", default=["k_trace2ILb0ELb0", "k_shadowILb0ELb0", "k_extendILb0", "k_shadeILb0", "k_resolve"])
+    ap.add_argument("names", nargs="*", default=["k_trace2ILb0ELb0", "k_shadowILb0ELb0", "k_extendILb0", "k_shadeILb0", "k_light", "k_resolve"])
     a = ap.parse_args()
-    ks = kernels(a.asm or compile_asm(a.src))
+    ks = {}
+    for f in (a.asm or [compile_asm(u) for u in a.src]):
+        ks.update(kernels(f))
     res = {}
     for sub in a.names:
         for name, body in ks.items():

@@ -59,7 +59,9 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--scene", default="dragon", help="dragon (stand-in), dragon-point (the stand-in with CBempty.dae's own point light: the earlier headline workload), bunny, spheres, or a .dae path")
+    ap.add_argument("--scene", default="dragon", help="dragon (stand-in), dragon-point (the stand-in with CBempty.dae's own point light: the earlier headline workload), "
+                         "folded (the irregular stand-in), lucy (stand-in; configuration 4 of the benchmark table with --width 1920 "
+                         "--height 1080 --depth 8), bunny, spheres (configuration 5 with --depth 16), or a .dae path")
     ap.add_argument("--specular", action="store_true",
                     help="ideal mirror / glass instead of the reference's black stubs (the divergent-specular "
                          "stress: --scene spheres --specular --depth 16)")
@@ -104,6 +106,19 @@ def resolve_scene(name, rank):
         if rank == 0:
             make_standin_scene.ensure("dragon", area_light=False)
         return path, "CBdragon stand-in with CBempty.dae's own point light (the earlier headline workload)", 1024
+    if name == "folded":
+        # a second, irregular stand-in of the same size: the knot's tube sampled non-uniformly (triangle areas span
+        # more than 1000 x), with deep lobes and a wobbling centre line so that sheets of surface overlap
+        path = make_standin_scene.standin_path("folded")
+        if rank == 0:
+            make_standin_scene.ensure("folded")
+        return path, "irregular stand-in (CB box and area light + 100k-triangle folded, non-uniformly tessellated tube)", 1024
+    if name == "lucy":
+        path = make_standin_scene.standin_path("lucy")
+        if rank == 0:
+            make_standin_scene.ensure("lucy")
+        return path, ("CBlucy stand-in (CB box and area light + 133k-triangle procedural knot; CBlucy.dae is absent from "
+                      "the reference checkout)"), 4096
     if name == "bunny":
         return os.path.join(ROOT, "scenes", "CBbunny.dae"), "CBbunny.dae", 256
     if name == "spheres":
@@ -179,22 +194,33 @@ def host_description():
 MIX_NAMES = {"extend": "k_extendILb0", "shadow": "k_shadowILb0ELb0", "shade": "k_shadeILb0", "resolve": "k_resolve",
              "trace2": "k_trace2ILb0ELb0", "light": "k_light"}
 KERNEL_NAMES = {"extend": "k_extend<false>", "shadow": "k_shadow<false, false>", "shade": "k_shade<false>",
-                "resolve": "k_resolve", "trace2": "k_trace2<false, false>"}
+                "resolve": "k_resolve", "trace2": "k_trace2<false, false>", "light": "k_light"}
 
 
-def profiled_counters(scene, kernel):
+def _profile_for(scene, workload):
+    """The latest committed counter summary of `scene` whose run was of this very workload (same scene,
+    frame size, sample counts and depth: the workload string of the line it recorded), or None."""
+    import glob
+    for path in reversed(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_summary.json" % scene)))):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        if workload is None or d.get("bench", {}).get("config", {}).get("workload") == workload:
+            return path, d
+    return None, None
+
+
+def profiled_counters(scene, kernel, workload=None):
     """Per-launch counter sums of `kernel` from the committed rocprofv3 passes of this workload
     (profiles/r*_<scene>_summary.json, written by tools/profile_round.sh): VALU lane-operations
     (SQ_THREAD_CYCLES_VALU: one count per active lane and VALU instruction), VALU instructions,
     cycles the SIMDs spent issuing them (SQ_ACTIVE_INST_VALU x 4), L2 requests, and the kernel's
     duration in that profile's kernel trace."""
-    import glob
-    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_summary.json" % scene)))
-    if kernel not in KERNEL_NAMES or not found:
+    path, d = _profile_for(scene, workload)
+    if kernel not in KERNEL_NAMES or not path:
         return None
-    path = found[-1]
     try:
-        d = json.load(open(path))
         k = KERNEL_NAMES[kernel]
         sq, sq2, grbm, l1 = d["pmc_sq"][k], d["pmc_sq2"][k], d["pmc_grbm"][k], d["pmc_l1"][k]
         n = sq2["_dispatches"]
@@ -220,18 +246,15 @@ def profiled_counters(scene, kernel):
         return None
 
 
-def profiled_traffic(scene, kernel):
+def profiled_traffic(scene, kernel, workload=None):
     """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this
     workload (profiles/, separate FETCH_SIZE and WRITE_SIZE runs). FETCH_SIZE is in KiB and,
     on gfx950, counts 128-byte read requests as 64 bytes, hence the factor 2."""
     names = KERNEL_NAMES
-    import glob
-    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_summary.json" % scene)))
-    if kernel not in names or not found:
+    path, d = _profile_for(scene, workload)  # the latest state profiled
+    if kernel not in names or not path:
         return None, None
-    path = found[-1]  # the latest state profiled
     try:
-        d = json.load(open(path))
         f = d["pmc_fetch"][names[kernel]]
         w = d["pmc_write"][names[kernel]]
         per_launch = (2.0 * f["FETCH_SIZE"] * 1024 / f["_dispatches"]) + (w["WRITE_SIZE"] * 1024 / w["_dispatches"])
@@ -412,11 +435,13 @@ def main():
                 rays = agg["two_ext"] + agg["two_shadow"]
                 roof["rays_per_launch_by_kind"] = {"bounce": agg["two_ext"] / n_launch, "shadow": agg["two_shadow"] / n_launch}
             roof["rays_per_launch"] = rays / n_launch
-        standard = args.scene in ("dragon", "bunny") and (args.width, args.height) == (800, 600) and not args.specular
+        # counters are taken from a committed profile only if it is of this very workload
+        standard = not args.specular and os.path.sep not in args.scene
+        wl = line["config"]["workload"]
         # ---- the binding ceiling of a BVH walk: VALU instruction issue. Lane-operations per launch come
         # from the committed counter passes of this same command line, the time per launch is measured
         # live (HIP events on the launch stream).
-        pc = profiled_counters(args.scene, names[dom]) if standard else None
+        pc = profiled_counters(args.scene, names[dom], wl) if standard else None
         if pc and (world > 1 or args.pixel_stride > 1):
             # the profile is of the whole frame on one GPU; a share of the frame has smaller launches. A
             # traversal kernel's work is proportional to its rays, which are counted live on both sides
@@ -465,7 +490,7 @@ def main():
                                    "achieved_gbs_at_64B": pc["l2_read_requests_per_launch"] * 64 / t_launch / 1e9,
                                    "peak": L2_PEAK_GBS}
         if standard and world == 1 and args.pixel_stride == 1:
-            tr, src = profiled_traffic(args.scene, names[dom])
+            tr, src = profiled_traffic(args.scene, names[dom], wl)
             roof["traffic"], roof["traffic_source"] = tr, src
             if tr and ms > 0:
                 g = tr / (ms * 1e-3 / n_launch) / 1e9

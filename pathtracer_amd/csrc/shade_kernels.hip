@@ -455,7 +455,13 @@ __global__ void LIGHT_BOUNDS
       // test and its rule (bvh.cpp:187: a hit strictly before the ray's end occludes); a ray they
       // occlude is never traced, and the walk of the others skips them.
       // (Measured and rejected: the walk's FP32 pre-test in front of each of these tests, which
-      // settles the triangle of the quad the sample point does not lie on: 9 % slower.)
+      // settles the triangle of the quad the sample point does not lie on: 9 % slower. A host-made
+      // table of the sample point's barycentric coordinates in each end triangle, which lets a lane
+      // pass over the triangle its ray certainly misses so that the wave runs the test once, each
+      // lane on its own triangle: the per-lane record costs more than the second test saves, whether
+      // loaded per lane (k_light 28.5 -> 30.9 ms) or picked out of the scalar-loaded records (34.0).
+      // A grid-stride loop instead of one workgroup per 256 slots: 30.5 to 31.8 ms. Compiled for 6 or
+      // 7 waves per SIMD instead of the 5 its 88 registers allow: 29.2 and 33.7 ms.)
       if (S.has_end && light_tag[li]) {
 #pragma unroll 1
         for (int k = 0; k < 4; k++) {

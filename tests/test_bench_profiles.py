@@ -14,13 +14,15 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
 
-@pytest.mark.parametrize("scene", ["dragon", "bunny"])
+@pytest.mark.parametrize("scene", ["dragon", "bunny", "lucy", "spheres", "folded"])
 def test_latest_profile_summary_feeds_the_roofline(scene):
     found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_summary.json" % scene)))
     assert found, "no committed profile summary for %s" % scene
     d = json.load(open(found[-1]))
-    for kernel in ("shadow", "trace2", "extend", "shade", "resolve"):
+    assert len(d.get("source_sha256", "")) == 64, "the summary does not say which device sources it was collected from"
+    for kernel in ("shadow", "trace2", "extend", "shade", "light", "resolve"):
         pc = bench.profiled_counters(scene, kernel)
+        assert isinstance(pc["stale"], bool) and pc["mean_cycles_per_inst"] and 2.0 <= pc["mean_cycles_per_inst"] <= 16.0
         assert pc is not None and pc["source"].endswith(os.path.basename(found[-1]))
         t = pc["trace_avg_launch_ms"] * 1e-3
         frac = pc["lane_ops_per_launch"] / t / 1e12 / bench.LANE_OPS_PEAK_T  # against 1024 SIMDs x 32 lanes x 2.4 GHz
@@ -32,4 +34,11 @@ def test_latest_profile_summary_feeds_the_roofline(scene):
         assert tr / t / 1e9 < bench.HBM_PEAK_GBS
     # the run the summary was made from reported the kernel the counters are scaled by
     assert d["bench"]["roofline"]["kernel"] in bench.KERNEL_NAMES
-    assert d["bench"]["roofline"].get("rays_per_launch", 0) > 0 or d["bench"]["roofline"]["kernel"] in ("shade", "resolve")
+    assert d["bench"]["roofline"].get("rays_per_launch", 0) > 0 or d["bench"]["roofline"]["kernel"] in ("shade", "resolve", "light")
+
+
+def test_a_profile_of_another_workload_is_not_used():
+    """Counters are scaled to the live run only when the committed profile is of the very same workload."""
+    assert bench.profiled_counters("dragon", "trace2", "some other workload") is None
+    d = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_dragon_summary.json")))[-1]))
+    assert bench.profiled_counters("dragon", "trace2", d["bench"]["config"]["workload"]) is not None

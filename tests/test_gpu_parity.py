@@ -299,7 +299,8 @@ def test_primary_hits_match_reference_golden(device, name, w, h):
         assert hashlib.sha256(ts.tobytes()).digest() == g["t_sha256_%d" % o].tobytes()
 
 
-@pytest.mark.parametrize("name,w,h", [("CBbunny", 800, 600), ("standin:dragon", 800, 600), ("standin:lucy", 1920, 1080)])
+@pytest.mark.parametrize("name,w,h", [("CBbunny", 800, 600), ("standin:dragon", 800, 600), ("standin:lucy", 1920, 1080),
+                                      ("standin:folded", 400, 300)])
 def test_primary_hits_match_reference_golden_at_benchmark_sizes(device, name, w, h):
     """The same bar on the frames of the benchmark table's configurations 2, 3 (the headline) and 4, at their
     full sizes: ids of every pixel against the reference's own BVHAccel::intersect, t bit for bit."""

@@ -83,7 +83,8 @@ def test_primary_hits_bit_exact(name, w, h):
             assert np.allclose(ts[::97], g["t_sub_%d" % o], rtol=1e-12, atol=0)
 
 
-@pytest.mark.parametrize("name,w,h", [("CBbunny", 800, 600), ("standin:dragon", 800, 600), ("standin:lucy", 1920, 1080)])
+@pytest.mark.parametrize("name,w,h", [("CBbunny", 800, 600), ("standin:dragon", 800, 600), ("standin:lucy", 1920, 1080),
+                                      ("standin:folded", 400, 300)])
 def test_primary_hits_bit_exact_at_benchmark_sizes(name, w, h):
     """The frames of the benchmark table's configurations 2, 3 and 4 (3 and 4: the stand-ins for the absent
     CBdragon.dae / CBlucy.dae): primitive ids of EVERY pixel and t bit for bit against the reference's own

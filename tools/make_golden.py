@@ -108,7 +108,10 @@ def primary_goldens_full_size():
     sc = dict(scenes())
     sc["CBdragon_standin"] = make_standin_scene.ensure("dragon")
     sc["CBlucy_standin"] = make_standin_scene.ensure("lucy")
-    primary_goldens(sc, (("CBbunny", 800, 600), ("CBdragon_standin", 800, 600), ("CBlucy_standin", 1920, 1080)))
+    # the irregular stand-in (folded, non-uniformly tessellated), at a reduced size
+    sc["CBfolded_standin"] = make_standin_scene.ensure("folded")
+    primary_goldens(sc, (("CBbunny", 800, 600), ("CBdragon_standin", 800, 600), ("CBlucy_standin", 1920, 1080),
+                         ("CBfolded_standin", 400, 300)))
 
 
 def render_goldens(sc):

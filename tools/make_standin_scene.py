@@ -12,6 +12,13 @@ writes byte-identical files.
 
     python tools/make_standin_scene.py dragon   # ~100k triangles -> scenes/_generated/CBdragon_standin.dae
     python tools/make_standin_scene.py lucy     # ~133k triangles -> scenes/_generated/CBlucy_standin.dae
+    python tools/make_standin_scene.py folded   # ~100k triangles -> scenes/_generated/CBfolded_standin.dae
+
+"folded" is a second, IRREGULAR stand-in of the dragon's size, there to tell how much of the
+traversal figures belongs to the knot's regularity: the same tube, but sampled non-uniformly along
+and around (triangle areas span more than 1000 x), with deep lobes and a sideways wobble of the
+tube's centre line so that the surface folds back over itself and sheets of it overlap: long thin
+triangles next to tiny ones, overlapping boxes, a worse tree. Same box, same light.
 """
 import os
 import sys
@@ -19,7 +26,7 @@ import sys
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-PRESETS = {"dragon": (512, 98), "lucy": (640, 104), "tiny": (48, 12)}
+PRESETS = {"dragon": (512, 98), "lucy": (640, 104), "tiny": (48, 12), "folded": (512, 98), "folded-tiny": (64, 16)}
 
 
 def knot_mesh(nu, nv):
@@ -49,11 +56,56 @@ def knot_mesh(nu, nv):
     return pts.astype(np.float32), tris
 
 
+def warp(t, depth, periods):
+    """Monotone map of [0, 2 pi) onto itself whose derivative swings between 1 - depth and 1 + depth."""
+    return t + depth * np.sin(periods * t) / periods
+
+
+def folded_mesh(nu, nv):
+    """The irregular stand-in: the knot's tube under non-uniform sampling, deep lobes and a wobbling centre line."""
+    s = np.linspace(0.0, 2 * np.pi, nu, endpoint=False)
+    u = warp(warp(s, 0.93, 5), 0.6, 17)  # spacing along the tube varies ~70 x
+    p, q = 2, 3
+    r = 0.30 + 0.12 * np.cos(q * u)
+    centre = np.stack([r * np.cos(p * u), 0.14 * np.sin(q * u), r * np.sin(p * u)], axis=1)
+    eps = 1e-4
+    up1 = u + eps
+    r1 = 0.30 + 0.12 * np.cos(q * up1)
+    tangent = np.stack([r1 * np.cos(p * up1), 0.14 * np.sin(q * up1), r1 * np.sin(p * up1)], axis=1) - centre
+    tangent /= np.linalg.norm(tangent, axis=1, keepdims=True)
+    up = np.array([0.0, 1.0, 0.0])
+    n1 = np.cross(tangent, up)
+    n1 /= np.linalg.norm(n1, axis=1, keepdims=True)
+    n2 = np.cross(tangent, n1)
+    # the centre line wobbles sideways faster than the tube is thick: neighbouring stretches of surface overlap
+    centre = centre + 0.035 * np.sin(23 * u)[:, None] * n1 + 0.03 * np.cos(31 * u)[:, None] * n2
+    t = np.linspace(0.0, 2 * np.pi, nv, endpoint=False)
+    v = warp(t, 0.9, 3)  # spacing around the tube varies ~19 x
+    uu, vv = np.meshgrid(u, v, indexing="ij")
+    tube = 0.085 * (1.0 + 0.55 * np.sin(5 * uu + 2 * vv) + 0.30 * np.cos(9 * vv - 4 * uu) + 0.12 * np.sin(29 * uu))
+    pts = (centre[:, None, :] + tube[..., None] * (np.cos(vv)[..., None] * n1[:, None, :] + np.sin(vv)[..., None] * n2[:, None, :]))
+    pts = pts.reshape(-1, 3) + np.array([0.0, 0.62, -0.05])
+    idx = np.arange(nu * nv).reshape(nu, nv)
+    a = idx
+    b = np.roll(idx, -1, axis=0)
+    c = np.roll(np.roll(idx, -1, axis=0), -1, axis=1)
+    d = np.roll(idx, -1, axis=1)
+    tris = np.concatenate([np.stack([a, b, c], axis=-1).reshape(-1, 3), np.stack([a, c, d], axis=-1).reshape(-1, 3)])
+    return pts.astype(np.float32), tris
+
+
+def triangle_area_spread(pts, tris):
+    """Largest over smallest triangle area, 99.9th over 0.1st percentile (for the scene's description)."""
+    p = pts.astype(np.float64)
+    ar = 0.5 * np.linalg.norm(np.cross(p[tris[:, 1]] - p[tris[:, 0]], p[tris[:, 2]] - p[tris[:, 0]]), axis=1)
+    return float(ar.max() / max(ar.min(), 1e-300)), float(np.percentile(ar, 99.9) / max(np.percentile(ar, 0.1), 1e-300))
+
+
 def write_scene(kind, out_path, area_light=True):
     """area_light=False keeps CBempty.dae's own light element, a point light (the scene of the earliest
     measurements)."""
     nu, nv = PRESETS[kind]
-    pts, tris = knot_mesh(nu, nv)
+    pts, tris = folded_mesh(nu, nv) if kind.startswith("folded") else knot_mesh(nu, nv)
     with open(os.path.join(ROOT, "scenes", "CBempty.dae")) as f:
         dae = f.read()
     # the file is Z_UP: the loader maps (x, y, z) -> (-x, z, y); invert that here
@@ -160,3 +212,6 @@ if __name__ == "__main__":
     k = sys.argv[1] if len(sys.argv) > 1 else "dragon"
     n = write_scene(k, standin_path(k))
     print("%s: %d triangles -> %s" % (k, n + 12, standin_path(k)))
+    nu_, nv_ = PRESETS[k]
+    print("triangle areas, largest / smallest and 99.9th / 0.1st percentile: %.0f, %.0f" % triangle_area_spread(
+        *(folded_mesh(nu_, nv_) if k.startswith("folded") else knot_mesh(nu_, nv_))))

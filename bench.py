@@ -334,7 +334,8 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     total_samples = 0
-    agg = {"ms": [0.0] * NK, "launches": [0] * NK, "rays": 0, "shadow": 0, "vertices": 0, "two_ext": 0, "two_shadow": 0}
+    agg = {"ms": [0.0] * NK, "launches": [0] * NK, "rays": 0, "shadow": 0, "vertices": 0, "two_ext": 0, "two_shadow": 0,
+           "unused": 0, "traced": 0}
     step_ms = []
     for i in range(args.steps):
         ts = time.perf_counter()
@@ -351,6 +352,8 @@ def main():
         agg["vertices"] += st.path_vertices
         agg["two_ext"] += st.two_ext_rays
         agg["two_shadow"] += st.two_shadow_rays
+        agg["unused"] += st.unused_slots
+        agg["traced"] += st.samples
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -381,6 +384,9 @@ def main():
                 workload_name, args.width, args.height, spp, args.light_samples, args.depth,
                 ", specular mode" if args.specular else ""),
                 "samples_per_step": total_samples // max(args.steps, 1),
+                # rank 0: samples its pixels kept, and path slots of its launches that held no sample
+                "samples_kept_by_rank0_per_step": agg["traced"] // max(args.steps, 1),
+                "unused_path_slots_per_step": agg["unused"] // max(args.steps, 1),
                 "parallelism": ("pixels dealt round-robin over %d GPU(s), " % world) +
                                ("once per frame, one all-gather at its end" if args.exchange == "frame" else
                                 "again after every adaptive round, one all-gather per round")},

@@ -135,6 +135,7 @@ typedef struct ptamd_stats {
   uint64_t two_ext_rays;   /* bounce rays traced by launches of class PTAMD_K_TRACE2 */
   uint64_t two_shadow_rays;/* shadow rays traced by launches of class PTAMD_K_TRACE2 */
   uint64_t exact_tests;    /* primitive tests the FP32 pre-test could not decide (counters enabled) */
+  uint64_t unused_slots;   /* path slots of a round's launches that held no sample (a pixel traced fewer batches than its neighbours) */
 } ptamd_stats;
 
 /* kernel classes for ptamd_stats.launches / kernel_ms */

@@ -55,7 +55,7 @@ class Stats(C.Structure):
                 ("nodes_visited", C.c_uint64), ("prim_tests", C.c_uint64),
                 ("launches", C.c_uint64 * 12), ("kernel_ms", C.c_double * 12),
                 ("two_ext_rays", C.c_uint64), ("two_shadow_rays", C.c_uint64),
-                ("exact_tests", C.c_uint64)]
+                ("exact_tests", C.c_uint64), ("unused_slots", C.c_uint64)]
 
 
 def make_params(w, h, ns_aa=1, max_ray_depth=1, accumulate_bounces=True, ns_area_light=1,

@@ -129,6 +129,30 @@ struct VertexBuf {
 struct PathBuf {
   double *rad[3];
   double *pend[3];
+  // the pixel and the sample index of a path slot (written by k_generate): the Philox key and counter words of its path
+  int32_t *pix, *smp;
+};
+// Where a chunk's pixels keep their paths. With every listed pixel tracing the same number of samples, pixel
+// p of the chunk owns slots [p ns, (p + 1) ns). When every pixel traces as many batches as ITS statistics
+// ask for (RoundPlan::planned), the slots are packed: pixel p owns [off[p], off[p + 1]), off being the
+// exclusive prefix sum of the planned counts (k_plan_*), so that a launch holds no unused slot.
+struct PathMap {
+  const uint32_t *off;       // [pixels of the chunk + 1], or null: ns slots per pixel
+  const uint32_t *slot_pix;  // packed: the pixel (index within the chunk) that owns slot 256 b, for every b
+  uint32_t ns;
+  __device__ __forceinline__ uint32_t first_slot(uint32_t p) const { return off ? off[p] : p * ns; }
+  // the pixel (index within the chunk) that owns slot k < off[np], and k's place among that pixel's slots
+  __device__ __forceinline__ uint32_t owner(uint32_t k, uint32_t np, uint32_t &sk) const {
+    if (!off) { sk = k % ns; return k / ns; }
+    // the owner of the 256-slot block's first slot, then at most 256 pixels further on
+    uint32_t lo = slot_pix[k >> 8], hi = lo + 257u < np ? lo + 257u : np;  // off[lo] <= k < off[hi]
+    while (hi - lo > 1) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (off[mid] <= k) lo = mid; else hi = mid;
+    }
+    sk = k - off[lo];
+    return lo;
+  }
 };
 
 // What a round traces for one pixel. With sample_base >= 0 the caller drives the

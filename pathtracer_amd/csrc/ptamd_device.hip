@@ -79,6 +79,7 @@ struct ptamd_context {
   // work buffers
   bool clear_ctl = false;  // the next ptamd_trace_list zeroes the device-side counters first
   double plan_margin = 1.5;  // RoundPlan::margin (PTAMD_PLAN_MARGIN in the environment: experiments)
+  int64_t predict_above = 1 << 20;  // rounds of fewer paths give every pixel all its samples (PTAMD_PREDICT_ABOVE)
   bool trace_two = true;  // bounce rays of depth d + 1 and shadow rays of depth d in one launch (PTAMD_TRACE_TWO=0: apart)
   uint32_t fuse_below = 16u << 20;  // ... when the two lists together are shorter than this (PTAMD_FUSE_BELOW)
   int64_t max_paths = 16 << 20;  // paths per launch: large launches amortise the drain of the slowest waves
@@ -93,6 +94,9 @@ struct ptamd_context {
   ShadowQ sq{};
   VertexBuf vb{};
   PathBuf pb{};
+  uint32_t *pix_off = nullptr;     // PathMap::off of the running chunk [cap_paths + 1]
+  uint32_t *plan_blocks = nullptr; // per-256-pixel sums of the planned counts [cap_paths / 256 + 2]
+  uint32_t *slot_pix = nullptr;    // PathMap::slot_pix [cap_paths / 256 + 2]
   Ctl *ctl = nullptr;
   uint32_t *block_count = nullptr;
   size_t block_count_cap = 0;
@@ -227,7 +231,7 @@ int ensure_buffers(ptamd_context *c, int64_t paths, int nls, bool pend) {
   auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
   size_t total = 0;
   auto take = [&](size_t bytes) { size_t o = total; total += al(bytes); return o; };
-  size_t off_q[2][10], off_hit[4], off_sq[5], off_vb[8], off_pb[6], off_list[2], off_cp[3], off_nee[4];
+  size_t off_q[2][10], off_hit[4], off_sq[5], off_vb[8], off_pb[6], off_list[2], off_cp[3], off_nee[4], off_map[5];
   for (int k = 0; k < 2; k++) {
     off_q[k][0] = take(P * 4);
     for (int j = 1; j < 10; j++) off_q[k][j] = take(P * 8);
@@ -246,6 +250,11 @@ int ensure_buffers(ptamd_context *c, int64_t paths, int nls, bool pend) {
   off_nee[3] = take(P * 16);
   for (int j = 0; j < 6; j++) off_pb[j] = take(P * 8);
   for (int k = 0; k < 2; k++) off_list[k] = take(P * 4);
+  off_map[0] = take(P * 4);
+  off_map[1] = take(P * 4);
+  off_map[2] = take((P + 1) * 4);
+  off_map[3] = take((P / 256 + 2) * 4);
+  off_map[4] = take((P / 256 + 2) * 4);
   off_cp[0] = take(P);
   off_cp[1] = take((P / 256 + 2) * 4);
   off_cp[2] = take((P / 256 + 2) * 4);
@@ -276,6 +285,11 @@ int ensure_buffers(ptamd_context *c, int64_t paths, int nls, bool pend) {
     c->pb.rad[j] = (double *)(b + off_pb[j]);
     c->pb.pend[j] = (double *)(b + off_pb[3 + j]);
   }
+  c->pb.pix = (int32_t *)(b + off_map[0]);
+  c->pb.smp = (int32_t *)(b + off_map[1]);
+  c->pix_off = (uint32_t *)(b + off_map[2]);
+  c->plan_blocks = (uint32_t *)(b + off_map[3]);
+  c->slot_pix = (uint32_t *)(b + off_map[4]);
   for (int k = 0; k < 2; k++) c->list[k] = (int32_t *)(b + off_list[k]);
   c->cp.pflag = (uint8_t *)(b + off_cp[0]);
   c->cp.cnt_next = (uint32_t *)(b + off_cp[1]);
@@ -340,6 +354,7 @@ int ptamd_create(int32_t device_id, ptamd_context **out) {
   if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) c->own_stream = nullptr;
   if (const char *e = getenv("PTAMD_TRACE_TWO")) c->trace_two = atoi(e) != 0;
   if (const char *e = getenv("PTAMD_FUSE_BELOW")) c->fuse_below = (uint32_t)strtoul(e, nullptr, 10);
+  if (const char *e = getenv("PTAMD_PREDICT_ABOVE")) c->predict_above = std::max<long long>(0, atoll(e));
   if (const char *e = getenv("PTAMD_PLAN_MARGIN")) { const double m = atof(e); if (m >= 1.0 && m <= 8.0) c->plan_margin = m; }
   // The counters live apart from the work buffers: those are reallocated when a later round needs
   // more room, and a frame's statistics must survive that.
@@ -598,14 +613,24 @@ int ptamd_trace_list(ptamd_context *c, const ptamd_pixel_list *list, int32_t sam
   const PixView pv = view_of(list);
   // per-pixel prediction only where a launch is big enough for dropped samples to cost time
   const RoundPlan rp{d_state, c->params.max_tolerance, sample_base, n_samples, c->params.samples_per_batch, c->params.ns_aa,
-                     n * n_samples >= (1 << 20) ? 1 : 0, c->plan_margin};
+                     n * n_samples >= c->predict_above ? 1 : 0, c->plan_margin};
+  // every pixel its own number of samples: the path slots are packed (PathMap), so the launches hold no unused slot
+  const bool packed = sample_base < 0;
+  const PathMap pm{packed ? (const uint32_t *)c->pix_off : nullptr, (const uint32_t *)c->slot_pix, (uint32_t)n_samples};
   Launcher L{c, s};
   const int depths = std::max(1, fp.max_ray_depth);
   for (int64_t p0 = 0; p0 < n; p0 += px_per_chunk) {
     const uint32_t up0 = (uint32_t)p0;
     L.begin(PTAMD_K_GENERATE);
-    hipLaunchKernelGGL(k_set_counts, 1, 1, 0, s, c->ctl, pv, up0, (uint32_t)px_per_chunk, (uint32_t)n_samples);
-    hipLaunchKernelGGL(k_generate, ggrid, 256, 0, s, fp, c->S, pv, up0, c->ctl, rp, c->q[0], pb);
+    if (packed) {
+      const uint32_t nb = (uint32_t)((std::min<int64_t>(px_per_chunk, n - p0) + 255) / 256);
+      hipLaunchKernelGGL(k_plan_count, nb, 256, 0, s, pv, up0, (uint32_t)px_per_chunk, rp, c->plan_blocks);
+      hipLaunchKernelGGL(k_plan_scan, 1, 1024, 0, s, c->plan_blocks, nb, c->ctl, pv, up0, (uint32_t)px_per_chunk);
+      hipLaunchKernelGGL(k_plan_offsets, nb, 256, 0, s, pv, up0, c->ctl, rp, (const uint32_t *)c->plan_blocks, c->pix_off, c->slot_pix);
+    } else {
+      hipLaunchKernelGGL(k_set_counts, 1, 1, 0, s, c->ctl, pv, up0, (uint32_t)px_per_chunk, (uint32_t)n_samples);
+    }
+    hipLaunchKernelGGL(k_generate, ggrid, 256, 0, s, fp, c->S, pv, up0, c->ctl, rp, pm, c->q[0], pb);
     L.end();
     int cur = 0;
     bool traced_ahead = false;  // this depth's bounce rays went with the previous depth's shadow rays (k_trace2)
@@ -626,10 +651,10 @@ int ptamd_trace_list(ptamd_context *c, const ptamd_pixel_list *list, int32_t sam
       L.begin(PTAMD_K_SHADE);
       if (fp.hemisphere)
         hipLaunchKernelGGL(k_shade<true>, shade_grid, 256, 0, s, fp, c->S, c->q[cur], lst, c->hb, c->q[cur ^ 1], c->sq, vb, pb,
-                           c->cp, c->ctl, depth, pv, up0, rp);
+                           c->cp, c->ctl, depth);
       else
         hipLaunchKernelGGL(k_shade<false>, shade_grid, 256, 0, s, fp, c->S, c->q[cur], lst, c->hb, c->q[cur ^ 1], c->sq, vb, pb,
-                           c->cp, c->ctl, depth, pv, up0, rp);
+                           c->cp, c->ctl, depth);
       L.end();
       if (!fp.hemisphere && fp.max_ray_depth > 0 && fp.nls > 0) {
         L.begin(PTAMD_K_LIGHT);
@@ -681,7 +706,7 @@ int ptamd_trace_list(ptamd_context *c, const ptamd_pixel_list *list, int32_t sam
       cur ^= 1;
     }
     L.begin(PTAMD_K_ACCUMULATE);
-    hipLaunchKernelGGL(k_accumulate, ggrid, 256, 0, s, pv, up0, c->ctl, rp, pb, d_state);
+    hipLaunchKernelGGL(k_accumulate, ggrid, 256, 0, s, pv, up0, c->ctl, rp, pm, pb, d_state);
     L.end();
   }
   HIPCHK(hipGetLastError());
@@ -836,6 +861,7 @@ int ptamd_get_stats(ptamd_context *c, ptamd_stats *out) {
     c->stats.samples = h.st_samples;
     c->stats.two_ext_rays = h.st_two_ext;
     c->stats.two_shadow_rays = h.st_two_shadow;
+    c->stats.unused_slots = h.st_dead;
   }
   *out = c->stats;
   return PTAMD_OK;

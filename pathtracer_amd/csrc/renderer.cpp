@@ -284,6 +284,7 @@ void RaytracedRenderer::start_raytracing() {  // raytraced_renderer.cpp:268-329
       stats.samples += part.samples; stats.rays += part.rays; stats.shadow_rays += part.shadow_rays;
       stats.path_vertices += part.path_vertices; stats.prim_tests += part.prim_tests; stats.nodes_visited += part.nodes_visited;
       stats.exact_tests += part.exact_tests; stats.two_ext_rays += part.two_ext_rays; stats.two_shadow_rays += part.two_shadow_rays;
+      stats.unused_slots += part.unused_slots;
       for (int k = 0; k < PTAMD_K_CLASSES; k++) { stats.launches[k] += part.launches[k]; stats.kernel_ms[k] += part.kernel_ms[k]; }
     }
   } else {

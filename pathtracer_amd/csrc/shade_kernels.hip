@@ -20,6 +20,84 @@ __global__ void k_set_counts(Ctl *ctl, PixView pv, uint32_t p0, uint32_t chunk, 
   ctl->grab[0] = ctl->grab[1] = ctl->grab[2] = 0;
 }
 
+// Packed path slots (PathMap): the planned sample counts of the chunk's pixels, summed per 256 pixels,
+// scanned, and turned into every pixel's first slot; the total is the chunk's number of paths.
+__global__ void k_plan_count(PixView pv, uint32_t p0, uint32_t chunk, RoundPlan rp, uint32_t *__restrict__ block_count) {
+  __shared__ uint32_t part[4];
+  const uint32_t have = pv.count();
+  const uint32_t np = have > p0 ? (have - p0 < chunk ? have - p0 : chunk) : 0u;
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t n = 0;
+  if (p < np) {
+    int32_t first;
+    n = (uint32_t)rp.planned(rp.state + (size_t)pv.at(p0 + p) * 6, first);
+  }
+  for (int off = 32; off > 0; off >>= 1) n += __shfl_down(n, off);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = n;
+  __syncthreads();
+  if (threadIdx.x == 0) block_count[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+// one workgroup: exclusive scan of the block sums in place; starts the chunk as k_set_counts does
+__global__ void __launch_bounds__(1024) k_plan_scan(uint32_t *block_count, uint32_t n_blocks, Ctl *ctl, PixView pv, uint32_t p0, uint32_t chunk) {
+  __shared__ uint32_t wtot[16];
+  __shared__ uint32_t carry;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (uint32_t base = 0; base < n_blocks; base += 1024) {
+    const uint32_t i = base + threadIdx.x;
+    const uint32_t v = i < n_blocks ? block_count[i] : 0u;
+    uint32_t x = v;
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t u = __shfl_up(x, off);
+      if (lane >= off) x += u;
+    }
+    if (lane == 63) wtot[wv] = x;
+    __syncthreads();
+    uint32_t pre = carry;
+    for (int k = 0; k < wv; k++) pre += wtot[k];
+    if (i < n_blocks) block_count[i] = pre + x - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry = pre + x;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const uint32_t have = pv.count();
+    ctl->n_pix = have > p0 ? (have - p0 < chunk ? have - p0 : chunk) : 0u;
+    ctl->n_cur = carry;
+    ctl->n_next = 0;
+    ctl->n_shadow = 0;
+    ctl->grab[0] = ctl->grab[1] = ctl->grab[2] = 0;
+  }
+}
+__global__ void k_plan_offsets(PixView pv, uint32_t p0, Ctl *ctl, RoundPlan rp, const uint32_t *__restrict__ block_offset,
+                               uint32_t *__restrict__ off, uint32_t *__restrict__ slot_pix) {
+  __shared__ uint32_t wtot[4];
+  const uint32_t np = ctl->n_pix;
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  uint32_t n = 0;
+  if (p < np) {
+    int32_t first;
+    n = (uint32_t)rp.planned(rp.state + (size_t)pv.at(p0 + p) * 6, first);
+  }
+  uint32_t x = n;
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t u = __shfl_up(x, o);
+    if (lane >= o) x += u;
+  }
+  if (lane == 63) wtot[wv] = x;
+  __syncthreads();
+  uint32_t pre = block_offset[blockIdx.x];
+  for (int k = 0; k < wv; k++) pre += wtot[k];
+  if (p < np) {
+    const uint32_t s0 = pre + x - n, s1 = pre + x;  // the pixel's slots
+    off[p] = s0;
+    for (uint32_t b = (s0 + 255u) >> 8; (b << 8) < s1; b++) slot_pix[b] = p;  // the 256-slot blocks that begin inside them
+  }
+  if (p + 1 == np) off[np] = pre + x;  // == ctl->n_cur
+}
+
 // end of one depth: fold the stage's counts into the statistics, make the next
 // queue current
 __global__ void k_advance(Ctl *ctl) {
@@ -42,26 +120,29 @@ __device__ __forceinline__ void camera_ray(const FrameParams &fp, double x, doub
 // One thread per path of the round: pixel = pixels[k / ns], sample = base + k % ns.
 // raytrace_pixel's ray set-up, src/pathtracer/pathtracer.cpp:259-261, with
 // JitteredSampler2D::get_sample (src/pathtracer/sampler.cpp:14-18).
-__global__ void k_generate(FrameParams fp, DevScene S, PixView pv, uint32_t p0, Ctl *ctl, RoundPlan rp, RayQ q, PathBuf pb) {
+__global__ void k_generate(FrameParams fp, DevScene S, PixView pv, uint32_t p0, Ctl *ctl, RoundPlan rp, PathMap pm, RayQ q, PathBuf pb) {
   const uint32_t stride = gridDim.x * blockDim.x;
-  const uint32_t n_paths = ctl->n_cur;
-  const int32_t ns = rp.ns;
+  const uint32_t n_paths = ctl->n_cur, np = ctl->n_pix;
   unsigned long long dead = 0;
   for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n_paths; k += stride) {
-    const int32_t pix = pv.at(p0 + k / (uint32_t)ns);
+    uint32_t usk;
+    const int32_t pix = pv.at(p0 + pm.owner(k, np, usk));
     int32_t first;
     const int32_t planned = rp.planned(rp.state + (size_t)pix * 6, first);
-    const int32_t sk = (int32_t)(k % (uint32_t)ns);
+    const int32_t sk = (int32_t)usk;
     q.path[k] = (int32_t)k;
     pb.rad[0][k] = 0; pb.rad[1][k] = 0; pb.rad[2][k] = 0;
     if (pb.pend[0]) { pb.pend[0][k] = 0; pb.pend[1][k] = 0; pb.pend[2][k] = 0; }
     if (sk >= planned) {
-      // a slot this round does not use: a zero direction tells k_extend to skip it
+      // a slot this round does not use (only where slots are not packed, see PathMap): a zero direction
+      // tells k_extend to skip it
       q.d[0][k] = 0; q.d[1][k] = 0; q.d[2][k] = 0;
       dead++;
       continue;
     }
     const int32_t s = first + sk;
+    pb.pix[k] = pix;
+    pb.smp[k] = s;
     const int32_t x = pix % fp.w, y = pix / fp.w;
     uint32_t wd[4];
     philox4x32_10((uint32_t)s, 0u, fp.seed_hi, 0u, fp.seed_lo, (uint32_t)pix, wd);
@@ -180,11 +261,10 @@ struct VisWriter {
 template <bool HEMI>
 __global__ void __launch_bounds__(256)
     k_shade(FrameParams fp, DevScene S, RayQ q, const int32_t *__restrict__ list, HitBuf hb, RayQ qn, ShadowQ sq,
-            VertexBuf vb, PathBuf pb, Compact cp, Ctl *ctl, int32_t depth, PixView pv, uint32_t p0, RoundPlan rp) {
+            VertexBuf vb, PathBuf pb, Compact cp, Ctl *ctl, int32_t depth) {
   __shared__ uint32_t wsum[2][4];
   const uint32_t n = ctl->n_cur;
   const int nls = fp.nls;
-  const int ns = rp.ns;
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   {
     // one workgroup per 256 entries (the grid covers the launch's upper bound; see ptamd_trace_list):
@@ -266,9 +346,8 @@ __global__ void __launch_bounds__(256)
           if (kind == PTAMD_MAT_DIFFUSE)
             f = vdivs(V(S.mat_param[3 * mat], S.mat_param[3 * mat + 1], S.mat_param[3 * mat + 2]), PT_PI);
           // the path's random numbers: key (seed, pixel), counter (sample, block)
-          const uint32_t k = (uint32_t)path;
-          rng_pix = (uint32_t)pv.at(p0 + k / (uint32_t)ns);
-          rng_s = (uint32_t)(rp.first_of(rp.state + (size_t)rng_pix * 6) + (int32_t)(k % (uint32_t)ns));
+          rng_pix = (uint32_t)pb.pix[path];
+          rng_s = (uint32_t)pb.smp[path];
           rng_base = 1u + (uint32_t)(depth - 1) * (uint32_t)fp.bpv;
           uint32_t wd[4];
           philox4x32_10(rng_s, rng_base, fp.seed_hi, 0u, fp.seed_lo, rng_pix, wd);
@@ -672,7 +751,7 @@ __global__ void k_resolve(FrameParams fp, DevScene S, RayQ q, const int32_t *__r
 // (One thread per pixel: its loads are not coalesced, but a wave per pixel with coalesced
 // loads and the ordered sum passed lane to lane was measured 2.5 times slower; the serial
 // additions, not the loads, are what a pixel costs.)
-__global__ void k_accumulate(PixView pv, uint32_t p0, Ctl *ctl, RoundPlan rp, PathBuf pb, double *__restrict__ state) {
+__global__ void k_accumulate(PixView pv, uint32_t p0, Ctl *ctl, RoundPlan rp, PathMap pm, PathBuf pb, double *__restrict__ state) {
   const uint32_t stride = gridDim.x * blockDim.x;
   const uint32_t n_pixels = ctl->n_pix;
   unsigned long long kept = 0;
@@ -682,7 +761,7 @@ __global__ void k_accumulate(PixView pv, uint32_t p0, Ctl *ctl, RoundPlan rp, Pa
     const int32_t planned = rp.planned(st, first);
     double acc[2] = {st[0], st[1]};
     v3 sum = V(st[2], st[3], st[4]);
-    const size_t b = (size_t)p * (uint32_t)rp.ns;
+    const size_t b = pm.first_slot(p);
     // runs of samples between two tests: inside a run nothing depends on the sums, so its loads
     // are issued eight at a time; the additions stay in sample order
     int s = 0;
@@ -722,8 +801,8 @@ __global__ void k_accumulate(PixView pv, uint32_t p0, Ctl *ctl, RoundPlan rp, Pa
 }
 
 template __global__ void k_shade<false>(FrameParams, DevScene, RayQ, const int32_t *, HitBuf, RayQ, ShadowQ, VertexBuf, PathBuf, Compact,
-                                        Ctl *, int32_t, PixView, uint32_t, RoundPlan);
+                                        Ctl *, int32_t);
 template __global__ void k_shade<true>(FrameParams, DevScene, RayQ, const int32_t *, HitBuf, RayQ, ShadowQ, VertexBuf, PathBuf, Compact,
-                                       Ctl *, int32_t, PixView, uint32_t, RoundPlan);
+                                       Ctl *, int32_t);
 
 }  // namespace ptk

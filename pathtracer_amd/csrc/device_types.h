@@ -96,7 +96,7 @@ struct HitBuf {
 };
 // Per light sample (slot = entry * nls + q) the records are arrays of structures
 // (shadow ray 32 bytes, contribution 24): the nls samples of one vertex are written by
-// one lane of k_shade as one contiguous run, and a shadow ray reads its record with
+// adjacent lanes of k_light as one contiguous run, and a shadow ray reads its record with
 // two 16-byte loads.
 struct alignas(32) SRay {
   double d[3];

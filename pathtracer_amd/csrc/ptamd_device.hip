@@ -1,11 +1,15 @@
 // Device layer of the render hot path for MI355X (gfx950): a wavefront path
-// tracer. One frame is rendered in rounds of one or more batches of
-// `samples_per_batch` samples per still-active pixel; each round runs, per path
-// depth,
+// tracer. This file is its host side: the C ABI of include/ptamd.h, the buffers, and the
+// round driver (ptamd_trace_list) that strings the kernels of trace_kernels.hip,
+// shade_kernels.hip and frame_kernels.hip together. One frame is rendered in rounds of one
+// or more batches of `samples_per_batch` samples per still-active pixel; each round runs,
+// per path depth,
 //
 //   extend   closest-hit BVH traversal of the ray list       (BVHAccel::intersect)
-//   shade    emission, Russian roulette, BSDF sample, light   (at_least_one_bounce_radiance,
-//            samples into fixed slots; per-block counts        estimate_direct_lighting_*)
+//   shade    emission, Russian roulette, BSDF sample, bounce  (at_least_one_bounce_radiance)
+//            ray; per-block counts
+//   light    the vertices' light samples into fixed slots,    (estimate_direct_lighting_*)
+//            one lane per sample
 //   scan2, scatter   ordered compaction: next ray list, shadow-ray list
 //   shadow   any-hit traversal of the shadow-ray list
 //   resolve  ordered sum of the unoccluded light samples
@@ -20,7 +24,7 @@
 // reference).
 //
 // All arithmetic that decides a result is FP64 in the reference's operation
-// order and this file is compiled with -ffp-contract=off. Queue sizes live on
+// order and the device layer is compiled with -ffp-contract=off. Queue sizes live on
 // the device; the host never synchronises inside a round.
 #include <hip/hip_runtime.h>
 
@@ -681,6 +685,10 @@ int ptamd_trace_list(ptamd_context *c, const ptamd_pixel_list *list, int32_t sam
           L.end();
           traced_ahead = true;
           shadow_skip = c->fuse_below;
+          // No list of this chunk can be longer than its path slots (bounce rays) and nls times that (shadow rays):
+          // when even those bounds stay below the threshold, k_trace2 always takes the shadow rays along and the
+          // launch of k_shadow, which would only find that out and return, is left out.
+          if (std::min<int64_t>(px_per_chunk, n - p0) * n_samples * (1 + (int64_t)nls) < (int64_t)c->fuse_below) shadow_skip = 0xffffffffu;
         }
         if (shadow_skip != 0xffffffffu) {  // (all lists fused: not even the empty launch)
           L.begin(PTAMD_K_SHADOW);

@@ -256,8 +256,8 @@ struct VisWriter {
 // ray's hit). Restates at_least_one_bounce_radiance (pathtracer.cpp:160-201)
 // iteratively: the path carries its throughput T, every shaded vertex adds
 // T * direct light.
-// (131 VGPRs, 3 waves per SIMD. Forcing 4 waves (127 registers, 2 spilled) gains 0.5 % at
-// most: the kernel is bound by its FP64 arithmetic and the bytes it moves, not by latency.)
+// (82 VGPRs. With the light-sample loop inside, one lane running all samples of its vertex, it was
+// 131: the samples now run one lane each in k_light.)
 template <bool HEMI>
 __global__ void __launch_bounds__(256)
     k_shade(FrameParams fp, DevScene S, RayQ q, const int32_t *__restrict__ list, HitBuf hb, RayQ qn, ShadowQ sq,

@@ -68,7 +68,7 @@ struct ShadowPolicy {
   FastDiv by_nls;  // slot -> entry (exact for slot < 2^31, nls < 2^16: both enforced by ptamd_trace_list)
   uint32_t nls, ns_area_light;
   __device__ __forceinline__ double min_t_all() const { return PT_EPS_D; }
-  // the tag of the light that sample q of a vertex goes to (k_shade's loop over the lights, backwards;
+  // the tag of the light that sample q of a vertex goes to (k_light's loop over the lights, backwards;
   // once per ray, and only in scenes where some light has end primitives: linear in the number of lights)
   __device__ __forceinline__ uint32_t light_tag_of(uint32_t q) const {
     for (int li = 0; li < S.n_lights; li++) {

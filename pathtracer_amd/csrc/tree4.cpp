@@ -117,7 +117,7 @@ int build_tree4(const ptamd_scene_desc *d, Tree4 &out) {
   // (max_t = distToLight, pathtracer.cpp:125): whether the quad occludes such a ray is decided
   // by the last bits of an FP64 test, which no float pre-test can settle, for every shadow ray
   // of the frame. So up to four triangles that lie in a light's plane and overlap its rectangle
-  // are listed per light (the first seven area or point lights that have any): k_shade runs the reference's test on them
+  // are listed per light (the first seven area or point lights that have any): k_light runs the reference's test on them
   // when it makes a shadow ray, and the ray's walk skips the primitives that carry its light's
   // tag. Which primitives are listed only decides where they are tested, not the result: a
   // shadow ray is occluded iff some primitive's test hits strictly before its end, in any order.

@@ -212,8 +212,8 @@ struct Walk {
       for (int a = 0; a < 3; a++) {
 #if PTAMD_PK_FMA
         // the two planes of an axis in one packed FMA (v_pk_fma_f32, the scale broadcast to both halves):
-        // measured 1 % slower than the two scalar FMAs (12 x 5.1 cycles against 24 x 3.4 should win; the
-        // register pairs it pins cost more), kept as a build option
+        // measured 1 % slower than the two scalar FMAs (a packed FMA issues every 4.3 cycles, a scalar one every
+        // 2.3: no flops to gain, and the register pairs it pins cost), kept as a build option
         const float2v qq = {(float)((qn[a] >> (8 * k)) & 0xffu), (float)((qf[a] >> (8 * k)) & 0xffu)};
         const float2v aa = {A[a], A[a]}, bb = {Bn[a], Bf[a]};
         const float2v tt = __builtin_elementwise_fma(qq, aa, bb);
@@ -231,7 +231,7 @@ struct Walk {
       t[k] = (c[k] != CHILD_EMPTY && !(lo2 > hi2)) ? lo2 : FINF;
     }
 #if PTAMD_NODE_TAGS
-    // A node some of whose children are end primitives of the light this shadow ray goes to (k_shade has
+    // A node some of whose children are end primitives of the light this shadow ray goes to (k_light has
     // tested them): they are passed over here, before they cost the lane a trip each. The node's header
     // names the tag, so the other nodes pay one comparison.
     {
@@ -311,7 +311,7 @@ struct Walk {
                                             const Dmin &self_dmin, bool first_hit = false) {
     const uint32_t code = ~(uint32_t)cur;
     const int p = (int)(code & PRIM_NONE);
-    // an end primitive of the light this shadow ray goes to: k_shade has tested it (and found no hit)
+    // an end primitive of the light this shadow ray goes to: k_light has tested it (and found no hit)
     if ((code >> PRIM_BITS) != 0u && (code >> PRIM_BITS) == (skip >> PRIM_BITS)) {
       pop(stack);
       return cur == CHILD_EMPTY;

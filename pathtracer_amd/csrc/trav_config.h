@@ -27,11 +27,14 @@
 #ifndef PTAMD_REFILL_EXTEND
 #define PTAMD_REFILL_EXTEND 24
 #endif
+// Shadow rays: 40 was best while the lists still held the rays that the light's own quad occludes; swept
+// again without them, 24 is 1 % faster per frame on the 100k-triangle scene and equal on CBbunny, 16 no
+// better there and 0.6 % slower on CBbunny, 8 and 48 slower on both.
 #ifndef PTAMD_REFILL_SHADOW
-#define PTAMD_REFILL_SHADOW 40
+#define PTAMD_REFILL_SHADOW 24
 #endif
 #ifndef PTAMD_REFILL_TWO_S
-#define PTAMD_REFILL_TWO_S 40  // the shadow-ray list of k_trace2
+#define PTAMD_REFILL_TWO_S 24  // the shadow-ray list of k_trace2
 #endif
 #ifndef PTAMD_WAVES_EXTEND
 #define PTAMD_WAVES_EXTEND 5  // the closest-hit walk with lane refill needs ~96 registers; spilling costs more than a wave

@@ -165,6 +165,58 @@ BODYS(k_g_cmpcnd32, G_CMPCND32)
 BODYS(k_g_cmpcnd64, G_CMPCND64)
 BODY(k_cndmask_set, float, INIT32V, I8(CNDM))
 BODY(k_cndmask_e64, float, INIT32V, I8(CNDM64))
+// candidates for a cheaper box test: mixed-precision FMA with an FP16 operand, byte permutes, three-operand
+// logic, integer and packed 16-bit min / max, FP16 and FP8 conversions
+#define FMAMIXLO(r) "v_fma_mix_f32 " r ", %11, %8, " r " op_sel_hi:[1,0,0]\n"
+#define FMAMIXHI(r) "v_fma_mix_f32 " r ", %11, %8, " r " op_sel:[1,0,0] op_sel_hi:[1,0,0]\n"
+#define PERMB32(r) "v_perm_b32 " r ", " r ", %11, %8\n"
+#define CVTF16(r) "v_cvt_f32_f16 " r ", %11\n"
+#define ANDOR(r) "v_and_or_b32 " r ", " r ", %11, %8\n"
+#define BFI(r) "v_bfi_b32 " r ", " r ", %11, %8\n"
+#define ALIGNBIT(r) "v_alignbit_b32 " r ", " r ", %11, 8\n"
+#define LSHLOR(r) "v_lshl_or_b32 " r ", " r ", 3, %11\n"
+#define LSHLADD(r) "v_lshl_add_u32 " r ", " r ", 3, %11\n"
+#define ADD3(r) "v_add3_u32 " r ", " r ", %11, %8\n"
+#define MAXI32(r) "v_max_i32 " r ", " r ", %11\n"
+#define MINU32(r) "v_min_u32 " r ", " r ", %11\n"
+#define MAX3I32(r) "v_max3_i32 " r ", " r ", %11, %8\n"
+#define PKMAXF16(r) "v_pk_max_f16 " r ", " r ", %11\n"
+#define PKFMAF16(r) "v_pk_fma_f16 " r ", " r ", %11, %8\n"
+#define PKMAXI16(r) "v_pk_max_i16 " r ", " r ", %11\n"
+#define PKADDU16(r) "v_pk_add_u16 " r ", " r ", %11\n"
+#define CMPU32(r) "v_cmp_lt_u32 vcc, " r ", %11\n"
+#define SUBREV(r) "v_subrev_f32 " r ", %8, " r "\n"
+#define DOT2(r) "v_dot2_f32_f16 " r ", %11, %11, " r "\n"
+#define DOT2C(r) "v_dot2c_f32_f16 " r ", %11, %11\n"
+#define CVTPKFP8(r) "v_cvt_pk_f32_fp8 " r ", %11\n"
+#define XAD(r) "v_xad_u32 " r ", " r ", %11, %8\n"
+#define OR3(r) "v_or3_b32 " r ", " r ", %11, %8\n"
+#define SDWAADD(r) "v_add_f32_sdwa " r ", " r ", %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n"
+BODY(k_fma_mix_lo, float, INIT32, I8(FMAMIXLO))
+BODY(k_fma_mix_hi, float, INIT32, I8(FMAMIXHI))
+BODY(k_perm_b32, float, INIT32, I8(PERMB32))
+BODY(k_cvt_f32_f16, float, INIT32, I8(CVTF16))
+BODY(k_and_or_b32, float, INIT32, I8(ANDOR))
+BODY(k_bfi_b32, float, INIT32, I8(BFI))
+BODY(k_alignbit_b32, float, INIT32, I8(ALIGNBIT))
+BODY(k_lshl_or_b32, float, INIT32, I8(LSHLOR))
+BODY(k_lshl_add_u32, float, INIT32, I8(LSHLADD))
+BODY(k_add3_u32, float, INIT32, I8(ADD3))
+BODY(k_max_i32, float, INIT32, I8(MAXI32))
+BODY(k_min_u32, float, INIT32, I8(MINU32))
+BODY(k_max3_i32, float, INIT32, I8(MAX3I32))
+BODY(k_pk_max_f16, float, INIT32, I8(PKMAXF16))
+BODY(k_pk_fma_f16, float, INIT32, I8(PKFMAF16))
+BODY(k_pk_max_i16, float, INIT32, I8(PKMAXI16))
+BODY(k_pk_add_u16, float, INIT32, I8(PKADDU16))
+BODY(k_cmp_lt_u32, float, INIT32, I8(CMPU32))
+BODY(k_subrev_f32, float, INIT32, I8(SUBREV))
+BODY(k_dot2_f32_f16, float, INIT32, I8(DOT2))
+BODY(k_dot2c_f32_f16, float, INIT32, I8(DOT2C))
+BODY(k_cvt_pk_f32_fp8, double, INIT64, I8(CVTPKFP8))
+BODY(k_xad_u32, float, INIT32, I8(XAD))
+BODY(k_or3_b32, float, INIT32, I8(OR3))
+BODY(k_add_f32_sdwa, float, INIT32, I8(SDWAADD))
 // half v_fma_f32, half v_fma_f64 (the f64 ones on the double d, throw-away results in a0..a3's place is
 // not possible with one register class, so the mix runs 4 + 4 on separate accumulators)
 __global__ void __launch_bounds__(256) k_mix_32_64(double *out, int iters, Stamp *st, unsigned long long mask) {
@@ -251,7 +303,34 @@ int main(int argc, char **argv) {
       {"1 cndmask_e32 + 7 fma_f32", k_g_cnd32, ALL, 40000},
       {"1 cndmask_e64 + 7 fma_f32", k_g_cnd64, ALL, 40000},
       {"cmp_e32 vcc + cndmask_e32", k_g_cmpcnd32, ALL, 40000},
-      {"cmp_e64 sgpr + cndmask_e64", k_g_cmpcnd64, ALL, 40000}};
+      {"cmp_e64 sgpr + cndmask_e64", k_g_cmpcnd64, ALL, 40000},
+      {"v_fma_mix_f32 f16 lo", k_fma_mix_lo, ALL, 40000},
+      {"v_fma_mix_f32 f16 hi", k_fma_mix_hi, ALL, 40000},
+      {"v_perm_b32", k_perm_b32, ALL, 40000},
+      {"v_cvt_f32_f16", k_cvt_f32_f16, ALL, 40000},
+      {"v_and_or_b32", k_and_or_b32, ALL, 40000},
+      {"v_bfi_b32", k_bfi_b32, ALL, 40000},
+      {"v_alignbit_b32", k_alignbit_b32, ALL, 40000},
+      {"v_lshl_or_b32", k_lshl_or_b32, ALL, 40000},
+      {"v_lshl_add_u32", k_lshl_add_u32, ALL, 40000},
+      {"v_add3_u32", k_add3_u32, ALL, 40000},
+      {"v_max_i32", k_max_i32, ALL, 40000},
+      {"v_min_u32", k_min_u32, ALL, 40000},
+      {"v_max3_i32", k_max3_i32, ALL, 40000},
+      {"v_pk_max_f16", k_pk_max_f16, ALL, 40000},
+      {"v_pk_fma_f16", k_pk_fma_f16, ALL, 40000},
+      {"v_pk_max_i16", k_pk_max_i16, ALL, 40000},
+      {"v_pk_add_u16", k_pk_add_u16, ALL, 40000},
+      {"v_cmp_lt_u32", k_cmp_lt_u32, ALL, 40000},
+      {"v_subrev_f32", k_subrev_f32, ALL, 40000},
+      {"v_dot2_f32_f16", k_dot2_f32_f16, ALL, 40000},
+      {"v_dot2c_f32_f16", k_dot2c_f32_f16, ALL, 40000},
+      {"v_cvt_pk_f32_fp8", k_cvt_pk_f32_fp8, ALL, 20000},
+      {"v_xad_u32", k_xad_u32, ALL, 40000},
+      {"v_or3_b32", k_or3_b32, ALL, 40000},
+      {"v_add_f32_sdwa", k_add_f32_sdwa, ALL, 40000}};
+  const size_t first_new = 53;  // "new": only the entries from here on, at 2 and 5 waves per SIMD
+  const bool only_new = argc > 1 && !strcmp(argv[1], "new");
   // warm the clocks up: two seconds of back-to-back launches
   {
     double *out; Stamp *st;
@@ -272,13 +351,15 @@ int main(int argc, char **argv) {
   }
   printf("device: %s, %d CUs\n", p.name, cus);
   printf("%-28s %6s %8s %6s %6s %9s %10s %10s\n", "instruction", "w/SIMD", "ms", "SIMDs", "res", "clock GHz", "cyc/instr", "cyc(wall)");
-  for (int wpe : {1, 2, 4, 5, 7, 8}) {  // waves per SIMD: 256 threads = 4 waves = one per SIMD of a CU
+  for (int wpe : {1, 2, 4, 5, 7, 8}) {
+    if (only_new && wpe != 2 && wpe != 5) continue;  // waves per SIMD: 256 threads = 4 waves = one per SIMD of a CU
     const int blocks = cus * wpe;
     double *out; Stamp *st;
     CHK(hipMalloc(&out, sizeof(double) * blocks * 256));
     CHK(hipMalloc(&st, sizeof(Stamp) * blocks * 4));
     for (const K &k : ks) {
       if (quick && k.mask != ALL) continue;
+      if (only_new && (size_t)(&k - ks) < first_new) continue;
       const int iters = k.iters / 8;  // 64 instructions per iteration
       hipEvent_t e0, e1;
       CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));

@@ -42,10 +42,18 @@ static void prim_box(const ptamd_scene_desc &d, int p, double bb[6]) {
     for (int k = 0; k < 3; k++) { bb[k] = P[k] - P[3]; bb[3 + k] = P[k] + P[3]; }
 }
 
-static WTree collapse(const ptamd_scene_desc &d, int W) {
+// leaves = true: a leaf of the binary tree (up to four primitives, src/scene/bvh.h:52) stays ONE child with the leaf's box, code ~(leaf node);
+// its primitives are then tested in one step, without boxes of their own
+static WTree collapse(const ptamd_scene_desc &d, int W, bool leaves = false) {
   struct Item { int node, prim; };
-  auto norm = [&](Item it) { return (it.node >= 0 && d.node_count[it.node] == 1) ? Item{-1, d.node_start[it.node]} : it; };
-  auto box_of = [&](Item it, double bb[6]) { if (it.node >= 0) for (int k = 0; k < 6; k++) bb[k] = d.node_bbox[6 * (size_t)it.node + k]; else prim_box(d, it.prim, bb); };
+  auto norm = [&](Item it) {
+    if (leaves) return (it.node >= 0 && d.node_count[it.node] > 0) ? Item{-1, it.node} : it;  // prim = the leaf NODE
+    return (it.node >= 0 && d.node_count[it.node] == 1) ? Item{-1, d.node_start[it.node]} : it;
+  };
+  auto box_of = [&](Item it, double bb[6]) {
+    if (it.node >= 0 || leaves) for (int k = 0; k < 6; k++) bb[k] = d.node_bbox[6 * (size_t)(it.node >= 0 ? it.node : it.prim) + k];
+    else prim_box(d, it.prim, bb);
+  };
   auto area = [](const double bb[6]) { const double ex = bb[3] - bb[0], ey = bb[4] - bb[1], ez = bb[5] - bb[2]; return ex * ey + ey * ez + ez * ex; };
   auto expand = [&](Item it, std::vector<Item> &out) {
     if (d.node_count[it.node] > 0) for (int p = d.node_start[it.node]; p < d.node_start[it.node] + d.node_count[it.node]; p++) out.push_back({-1, p});
@@ -119,7 +127,7 @@ static bool prim_hit(const ptamd_scene_desc &d, int p, V3 o, V3 dir, double tmin
   return false;
 }
 
-struct Counts { double rays = 0, visits = 0, boxes = 0, tests = 0, trips = 0; };
+struct Counts { double rays = 0, visits = 0, boxes = 0, tests = 0, trips = 0, leaf_steps = 0; };
 // one lane of the device schedule: a trip = up to two node steps, then a primitive step if the lane is at a primitive
 struct TripMeter {
   int slot = 0; long trips = 0;  // slot: 0, 1 = node slots, 2 = primitive slot of the running trip
@@ -127,7 +135,7 @@ struct TripMeter {
   void prim() { if (trips == 0) trips = 1; if (slot > 2) { trips++; } slot = 3; }
 };
 
-static int trace(const ptamd_scene_desc &d, const WTree &T, V3 o, V3 dir, double tmin, double tmax, bool first_hit, Counts &C, int skip_prim) {
+static int trace(const ptamd_scene_desc &d, const WTree &T, V3 o, V3 dir, double tmin, double tmax, bool first_hit, Counts &C, int skip_prim, bool leaves = false) {
   const V3 inv{1 / dir.x, 1 / dir.y, 1 / dir.z};
   struct E { int code; double t; };
   std::vector<E> st{{0, 0.0}};
@@ -137,6 +145,19 @@ static int trace(const ptamd_scene_desc &d, const WTree &T, V3 o, V3 dir, double
   while (!st.empty()) {
     const E e = st.back(); st.pop_back();
     if (e.t > best) continue;
+    if (e.code < 0 && leaves) {
+      const int leaf = ~e.code;
+      C.leaf_steps++; tm.prim();
+      bool done = false;
+      for (int p = d.node_start[leaf]; p < d.node_start[leaf] + d.node_count[leaf]; p++) {
+        if (p == skip_prim) continue;
+        C.tests++;
+        double t;
+        if (prim_hit(d, p, o, dir, tmin, best, t) && (t < best || hit < 0)) { best = t; hit = p; if (first_hit) { done = true; break; } }
+      }
+      if (done) break;
+      continue;
+    }
     if (e.code < 0) {
       const int p = ~e.code;
       if (p == skip_prim) continue;
@@ -170,8 +191,10 @@ int main(int argc, char **argv) {
   int la = -1;
   for (int li = 0; li < d.n_lights; li++) if (d.light_kind[li] == PTAMD_LIGHT_AREA) { la = li; break; }
   printf("%s: %d primitives, %d binary nodes\n", argv[1], d.n_prims, d.n_nodes);
-  for (int W : {2, 4, 8, 16}) {
-    const WTree T = collapse(d, W);
+  for (int mode = 0; mode < 6; mode++) {
+    const int W = mode < 4 ? (2 << mode) : (mode == 4 ? 4 : 8);
+    const bool leaves = mode >= 4;
+    const WTree T = collapse(d, W, leaves);
     size_t children = 0, prim_children = 0;
     for (auto &n : T.nodes) { children += n.child.size(); for (int c : n.child) prim_children += c < 0; }
     Counts cam_c, bounce_c, shadow_c;
@@ -194,8 +217,8 @@ int main(int argc, char **argv) {
           static int last = -1;
           if (depth == 0) last = -1;
           Counts tmp;
-          const int p = trace(d, T, o, dir, depth == 0 ? cam.nClip : 1e-11, depth == 0 ? cam.fClip : INFINITY, false, tmp, last);
-          C.rays += tmp.rays; C.visits += tmp.visits; C.boxes += tmp.boxes; C.tests += tmp.tests; C.trips += tmp.trips;
+          const int p = trace(d, T, o, dir, depth == 0 ? cam.nClip : 1e-11, depth == 0 ? cam.fClip : INFINITY, false, tmp, last, leaves);
+          C.rays += tmp.rays; C.visits += tmp.visits; C.boxes += tmp.boxes; C.tests += tmp.tests; C.trips += tmp.trips; C.leaf_steps += tmp.leaf_steps;
           if (p < 0) break;
           // the hit point and a geometric normal facing the ray
           double t; prim_hit(d, p, o, dir, depth == 0 ? cam.nClip : 1e-11, INFINITY, t);
@@ -211,7 +234,7 @@ int main(int argc, char **argv) {
               const V3 S{L[3] + L[9] * ax + L[12] * ay, L[4] + L[10] * ax + L[13] * ay, L[5] + L[11] * ax + L[14] * ay};
               const V3 dd = S - hp; const double dist = std::sqrt(dot(dd, dd));
               if (dot(dd, n) <= 0) continue;
-              trace(d, T, hp, dd * (1 / dist), 1e-11, dist * (1 - 1e-6), true, shadow_c, p);
+              trace(d, T, hp, dd * (1 / dist), 1e-11, dist * (1 - 1e-6), true, shadow_c, p, leaves);
             }
           }
           // cosine-weighted bounce
@@ -223,11 +246,13 @@ int main(int argc, char **argv) {
         }
       }
     auto pr = [&](const char *k, const Counts &C) {
-      printf("  W=%2d %-7s rays %8.0f  node visits %6.2f  boxes %6.2f  primitive tests %5.2f  lane trips %5.2f\n", W, k, C.rays, C.visits / C.rays,
+      printf("  W=%2d %-7s rays %8.0f  node visits %6.2f  boxes %6.2f  primitive tests %5.2f  lane trips %5.2f", W, k, C.rays, C.visits / C.rays,
              C.boxes / C.rays, C.tests / C.rays, C.trips / C.rays);
+      if (leaves) printf("  leaf steps %5.2f", C.leaf_steps / C.rays);
+      printf("\n");
     };
-    printf(" W=%d: %zu nodes, %.2f children per node (%.2f of them primitives)\n", W, T.nodes.size(), (double)children / T.nodes.size(),
-           (double)prim_children / T.nodes.size());
+    printf(" W=%d%s: %zu nodes, %.2f children per node (%.2f of them %s)\n", W, leaves ? " with whole leaves" : "", T.nodes.size(),
+           (double)children / T.nodes.size(), (double)prim_children / T.nodes.size(), leaves ? "leaves" : "primitives");
     pr("camera", cam_c); pr("bounce", bounce_c); pr("shadow", shadow_c);
   }
   ptamd_scene_free(sc);

@@ -129,8 +129,9 @@ struct VertexBuf {
 struct PathBuf {
   double *rad[3];
   double *pend[3];
-  // the pixel and the sample index of a path slot (written by k_generate): the Philox key and counter words of its path
-  int32_t *pix, *smp;
+  // the pixel and the sample index of a path slot (written by k_generate): the Philox key and counter words of its
+  // path, side by side (one 8-byte gather per vertex instead of two of 4)
+  int2 *pix_smp;
 };
 // Where a chunk's pixels keep their paths. With every listed pixel tracing the same number of samples, pixel
 // p of the chunk owns slots [p ns, (p + 1) ns). When every pixel traces as many batches as ITS statistics

@@ -254,8 +254,8 @@ int ensure_buffers(ptamd_context *c, int64_t paths, int nls, bool pend) {
   off_nee[3] = take(P * 16);
   for (int j = 0; j < 6; j++) off_pb[j] = take(P * 8);
   for (int k = 0; k < 2; k++) off_list[k] = take(P * 4);
-  off_map[0] = take(P * 4);
-  off_map[1] = take(P * 4);
+  off_map[0] = take(P * 8);
+  off_map[1] = 0;
   off_map[2] = take((P + 1) * 4);
   off_map[3] = take((P / 256 + 2) * 4);
   off_map[4] = take((P / 256 + 2) * 4);
@@ -289,8 +289,7 @@ int ensure_buffers(ptamd_context *c, int64_t paths, int nls, bool pend) {
     c->pb.rad[j] = (double *)(b + off_pb[j]);
     c->pb.pend[j] = (double *)(b + off_pb[3 + j]);
   }
-  c->pb.pix = (int32_t *)(b + off_map[0]);
-  c->pb.smp = (int32_t *)(b + off_map[1]);
+  c->pb.pix_smp = (int2 *)(b + off_map[0]);
   c->pix_off = (uint32_t *)(b + off_map[2]);
   c->plan_blocks = (uint32_t *)(b + off_map[3]);
   c->slot_pix = (uint32_t *)(b + off_map[4]);

@@ -141,8 +141,7 @@ __global__ void k_generate(FrameParams fp, DevScene S, PixView pv, uint32_t p0, 
       continue;
     }
     const int32_t s = first + sk;
-    pb.pix[k] = pix;
-    pb.smp[k] = s;
+    pb.pix_smp[k] = make_int2(pix, s);
     const int32_t x = pix % fp.w, y = pix / fp.w;
     uint32_t wd[4];
     philox4x32_10((uint32_t)s, 0u, fp.seed_hi, 0u, fp.seed_lo, (uint32_t)pix, wd);
@@ -296,7 +295,8 @@ __global__ void __launch_bounds__(256)
         }
         vb.flag[i] = 0;
       } else {
-        const int32_t info = S.prim_info[prim];
+        // (bit 0: sphere, bits 1..: material; the copy in the primitive's FP64 record, which exact_test reads anyway)
+        const int32_t info = low_word(S.prim[(size_t)prim * PRIM_STRIDE + 9]);
         const int32_t mat = info >> 1;
         nee_mat = mat;
         const int32_t kind = S.mat_kind[mat];
@@ -346,8 +346,9 @@ __global__ void __launch_bounds__(256)
           if (kind == PTAMD_MAT_DIFFUSE)
             f = vdivs(V(S.mat_param[3 * mat], S.mat_param[3 * mat + 1], S.mat_param[3 * mat + 2]), PT_PI);
           // the path's random numbers: key (seed, pixel), counter (sample, block)
-          rng_pix = (uint32_t)pb.pix[path];
-          rng_s = (uint32_t)pb.smp[path];
+          const int2 ps = pb.pix_smp[path];
+          rng_pix = (uint32_t)ps.x;
+          rng_s = (uint32_t)ps.y;
           rng_base = 1u + (uint32_t)(depth - 1) * (uint32_t)fp.bpv;
           uint32_t wd[4];
           philox4x32_10(rng_s, rng_base, fp.seed_hi, 0u, fp.seed_lo, rng_pix, wd);

@@ -192,9 +192,14 @@ def host_description():
 
 # keys of a summary's `isa_mix` (tools/isa_mix.py: substrings of the mangled kernel names)
 MIX_NAMES = {"extend": "k_extendILb0", "shadow": "k_shadowILb0ELb0", "shade": "k_shadeILb0", "resolve": "k_resolve",
-             "trace2": "k_trace2ILb0ELb0", "light": "k_light"}
-KERNEL_NAMES = {"extend": "k_extend<false>", "shadow": "k_shadow<false, false>", "shade": "k_shade<false>",
-                "resolve": "k_resolve", "trace2": "k_trace2<false, false>", "light": "k_light"}
+             "trace2": "k_trace2ILb0ELb0", "light": "k_light_resolve", "light_alone": "k_lightE", "light_resolve": "k_light_resolve"}
+# Kernels of a timing class (ptamd_stats.kernel_ms). The class "light" times every launch that draws light samples:
+# k_light (a round's first depth) and k_light_resolve (a later depth's light sampling with the previous depth's
+# k_resolve in the same launch); its counters are the sums over both. "resolve" is what is left of k_resolve, the
+# last depth's launch.
+KERNEL_NAMES = {"extend": ("k_extend<false>",), "shadow": ("k_shadow<false, false>",), "shade": ("k_shade<false>",),
+                "resolve": ("k_resolve",), "trace2": ("k_trace2<false, false>",), "light": ("k_light", "k_light_resolve"),
+                "light_alone": ("k_light",), "light_resolve": ("k_light_resolve",)}
 
 
 def _profile_for(scene, workload):
@@ -211,34 +216,44 @@ def _profile_for(scene, workload):
     return None, None
 
 
+def _pass_sum(d, pmc_pass, kernels, counter):
+    """(sum of `counter` over the profiled launches of `kernels`, number of those launches) in one counter pass."""
+    rows = [d[pmc_pass][k] for k in kernels if k in d[pmc_pass]]
+    if not rows:
+        raise KeyError(kernels)
+    return sum(r[counter] for r in rows), sum(r["_dispatches"] for r in rows)
+
+
 def profiled_counters(scene, kernel, workload=None):
-    """Per-launch counter sums of `kernel` from the committed rocprofv3 passes of this workload
+    """Per-launch counter sums of the timing class `kernel` from the committed rocprofv3 passes of this workload
     (profiles/r*_<scene>_summary.json, written by tools/profile_round.sh): VALU lane-operations
     (SQ_THREAD_CYCLES_VALU: one count per active lane and VALU instruction), VALU instructions,
-    cycles the SIMDs spent issuing them (SQ_ACTIVE_INST_VALU x 4), L2 requests, and the kernel's
-    duration in that profile's kernel trace."""
+    cycles the SIMDs spent issuing them (SQ_ACTIVE_INST_VALU x 4), L2 requests, and the average
+    duration of a launch in that profile's kernel trace."""
     path, d = _profile_for(scene, workload)
     if kernel not in KERNEL_NAMES or not path:
         return None
     try:
-        k = KERNEL_NAMES[kernel]
-        sq, sq2, grbm, l1 = d["pmc_sq"][k], d["pmc_sq2"][k], d["pmc_grbm"][k], d["pmc_l1"][k]
-        n = sq2["_dispatches"]
+        ks = KERNEL_NAMES[kernel]
+        per = lambda p, c: (lambda t: t[0] / t[1])(_pass_sum(d, p, ks, c))  # noqa: E731
+        n = _pass_sum(d, "pmc_sq2", ks, "SQ_THREAD_CYCLES_VALU")[1]
         mix = (d.get("isa_mix") or {}).get(MIX_NAMES.get(kernel, ""), {})
         try:
             from summarize_prof import device_source_hash
             stale = d.get("source_sha256") != device_source_hash(ROOT)
         except Exception:
             stale = None
+        traced = [d["kernels"][k] for k in ks if k in d["kernels"]]
+        hit, miss = _pass_sum(d, "pmc_l2", ks, "TCC_HIT_sum")[0], _pass_sum(d, "pmc_l2", ks, "TCC_MISS_sum")[0]
         return {"source": os.path.relpath(path, ROOT), "launches": n, "stale": stale,
                 "mean_cycles_per_inst": mix.get("mean_cycles"),
-                "lane_ops_per_launch": sq2["SQ_THREAD_CYCLES_VALU"] / n,
-                "valu_insts_per_launch": sq["SQ_INSTS_VALU"] / sq["_dispatches"],
-                "valu_issue_cycles_per_launch": 4.0 * sq["SQ_ACTIVE_INST_VALU"] / sq["_dispatches"],
-                "gpu_cycles_per_launch": grbm["GRBM_GUI_ACTIVE"] / 8.0 / grbm["_dispatches"],
-                "l2_read_requests_per_launch": l1["TCP_TCC_READ_REQ_sum"] / l1["_dispatches"],
-                "trace_avg_launch_ms": d["kernels"][k]["avg_us"] / 1e3,
-                "l2_hit": d["pmc_l2"][k]["TCC_HIT_sum"] / max(d["pmc_l2"][k]["TCC_HIT_sum"] + d["pmc_l2"][k]["TCC_MISS_sum"], 1),
+                "lane_ops_per_launch": per("pmc_sq2", "SQ_THREAD_CYCLES_VALU"),
+                "valu_insts_per_launch": per("pmc_sq", "SQ_INSTS_VALU"),
+                "valu_issue_cycles_per_launch": 4.0 * per("pmc_sq", "SQ_ACTIVE_INST_VALU"),
+                "gpu_cycles_per_launch": per("pmc_grbm", "GRBM_GUI_ACTIVE") / 8.0,
+                "l2_read_requests_per_launch": per("pmc_l1", "TCP_TCC_READ_REQ_sum"),
+                "trace_avg_launch_ms": sum(t["total_ms"] for t in traced) / sum(t["calls"] for t in traced),
+                "l2_hit": hit / max(hit + miss, 1),
                 # rays per launch of the profiled run, when this kernel was the one it reported on
                 "rays_per_launch": (d.get("bench", {}).get("roofline", {}).get("rays_per_launch")
                                     if d.get("bench", {}).get("roofline", {}).get("kernel") == kernel else None)}
@@ -247,17 +262,16 @@ def profiled_counters(scene, kernel, workload=None):
 
 
 def profiled_traffic(scene, kernel, workload=None):
-    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this
+    """HBM-side bytes per launch of the timing class `kernel` from the committed rocprofv3 PMC passes of this
     workload (profiles/, separate FETCH_SIZE and WRITE_SIZE runs). FETCH_SIZE is in KiB and,
     on gfx950, counts 128-byte read requests as 64 bytes, hence the factor 2."""
-    names = KERNEL_NAMES
     path, d = _profile_for(scene, workload)  # the latest state profiled
-    if kernel not in names or not path:
+    if kernel not in KERNEL_NAMES or not path:
         return None, None
     try:
-        f = d["pmc_fetch"][names[kernel]]
-        w = d["pmc_write"][names[kernel]]
-        per_launch = (2.0 * f["FETCH_SIZE"] * 1024 / f["_dispatches"]) + (w["WRITE_SIZE"] * 1024 / w["_dispatches"])
+        f, nf = _pass_sum(d, "pmc_fetch", KERNEL_NAMES[kernel], "FETCH_SIZE")
+        w, nw = _pass_sum(d, "pmc_write", KERNEL_NAMES[kernel], "WRITE_SIZE")
+        per_launch = (2.0 * f * 1024 / nf) + (w * 1024 / nw)
         return per_launch, os.path.relpath(path, ROOT)
     except Exception:
         return None, None
@@ -470,8 +484,9 @@ def main():
                               "%d SIMDs x %d lanes x %.1f GHz (full-rate wave64 instruction every %g cycles, measured: "
                               "profiles/r03_valu_rates.txt)" % (N_SIMD, SIMD_LANES, CLOCK_HZ / 1e9, FULL_RATE_CYCLES),
                 "lane_ops_per_launch": pc["lane_ops_per_launch"],
-                "lane_ops_per_ray": pc["lane_ops_per_launch"] / max(roof.get("rays_per_launch") or 1, 1),
-                "valu_insts_per_ray": 64.0 * pc["valu_insts_per_launch"] / max(roof.get("rays_per_launch") or 1, 1),
+                # (per ray only where the kernel traces rays)
+                "lane_ops_per_ray": pc["lane_ops_per_launch"] / roof["rays_per_launch"] if roof.get("rays_per_launch") else None,
+                "valu_insts_per_ray": 64.0 * pc["valu_insts_per_launch"] / roof["rays_per_launch"] if roof.get("rays_per_launch") else None,
                 # VALU instructions per SIMD cycle of the profiled launch (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs),
                 # and of the 64 lanes of those instructions the share that was switched on
                 "valu_insts_per_simd_cycle": pc["valu_insts_per_launch"] / (pc["gpu_cycles_per_launch"] * N_SIMD),

@@ -8,6 +8,7 @@ MAT_DIFFUSE, MAT_EMISSION, MAT_MIRROR, MAT_MICROFACET, MAT_REFRACTION, MAT_GLASS
 LIGHT_DIRECTIONAL, LIGHT_INF_HEMISPHERE, LIGHT_POINT, LIGHT_SPOT, LIGHT_AREA = range(5)
 K_NAMES = ("generate", "extend", "shade", "shadow", "resolve", "accumulate", "filter", "other", "trace2",
            "light", "class10", "class11")
+K_RESOLVE = 4
 K_TRACE2 = 8
 K_LIGHT = 9
 

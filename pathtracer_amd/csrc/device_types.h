@@ -63,6 +63,7 @@ struct FrameParams {
 
 struct Ctl {
   uint32_t n_cur, n_next, n_shadow, n_pix;  // sizes of the ray lists; pixels of the running chunk
+  uint32_t n_prev, pad_;  // the previous depth's n_cur (k_advance): k_light_resolve settles that depth's light samples
   uint32_t grab[4];  // next unclaimed ray of a list: [0] k_extend, [1] shadow rays, [2] bounce rays in k_trace2 (persistent drivers)
   unsigned long long st_rays, st_shadow, st_vertices, st_nodes, st_tests, st_samples, st_dead;
   unsigned long long st_exact;  // primitive tests that needed the FP64 path (counted with st_tests)
@@ -132,6 +133,15 @@ struct PathBuf {
   // the pixel and the sample index of a path slot (written by k_generate): the Philox key and counter words of its
   // path, side by side (one 8-byte gather per vertex instead of two of 4)
   int2 *pix_smp;
+};
+// What k_resolve needs of a depth, for the launch that settles it beside the next depth's light samples (k_light_resolve)
+struct ResolveArgs {
+  RayQ q;
+  const int32_t *list;
+  VertexBuf vb;
+  const SRay *rays;
+  PathBuf pb;
+  int32_t depth;
 };
 // Where a chunk's pixels keep their paths. With every listed pixel tracing the same number of samples, pixel
 // p of the chunk owns slots [p ns, (p + 1) ns). When every pixel traces as many batches as ITS statistics

@@ -37,10 +37,8 @@ __global__ void k_scatter(Compact cp, VertexBuf vb, int32_t *__restrict__ list_n
 __global__ void k_resolve(FrameParams fp, DevScene S, RayQ q, const int32_t *__restrict__ list, VertexBuf vb,
                           const SRay *__restrict__ rays, PathBuf pb, Ctl *ctl, int32_t depth);
 __global__ void k_accumulate(PixView pv, uint32_t p0, Ctl *ctl, RoundPlan rp, PathMap pm, PathBuf pb, double *__restrict__ state);
-// workgroups per CU of a grid-stride k_light (0: one workgroup per 256 slots of the launch's upper bound)
-#ifndef PTAMD_LIGHT_LOOP
-#define PTAMD_LIGHT_LOOP 0
-#endif
+__global__ void k_light_resolve(FrameParams fp, DevScene S, VertexBuf vb, ShadowQ sq, Compact cp, Ctl *ctl, FastDiv by_nls, uint32_t rng_base,
+                                ResolveArgs prev);
 
 // ---- frame_kernels.hip
 __global__ void k_filter_count(PixView pv, int32_t n_done, double tol, int32_t batch, int32_t ns_aa,

@@ -90,8 +90,17 @@ struct ptamd_context {
   int64_t cap_paths = 0;
   int cap_nls = 0;
   bool cap_pend = false;
+  bool cap_dup = false;  // the per-depth second copies exist (see fuse_resolve)
   void *slab = nullptr;
-  RayQ q[2]{};
+  RayQ q[3]{};  // two in turn; the third only where a depth's queue must outlive the next depth's shading (fuse_resolve)
+  // k_resolve of depth d beside k_light of depth d + 1 (k_light_resolve): the records the two would share are then
+  // kept per depth parity, [0] being the copies of vb / sq (PTAMD_FUSE_RESOLVE=0: one after the other)
+  bool fuse_resolve = true;
+  uint8_t *flag_p[2]{nullptr, nullptr};
+  Contrib *contrib_p[2]{nullptr, nullptr};
+  uint8_t *vis_p[2]{nullptr, nullptr};
+  int32_t *pend_prim_p[2]{nullptr, nullptr};
+  SRay *ray_p[2]{nullptr, nullptr};
   int32_t *list[2]{nullptr, nullptr};
   Compact cp{};
   HitBuf hb{};
@@ -221,8 +230,8 @@ void collect_events(ptamd_context *c) {
   c->events.clear();
 }
 
-int ensure_buffers(ptamd_context *c, int64_t paths, int nls, bool pend) {
-  if (c->slab && c->cap_paths >= paths && c->cap_nls >= nls && (c->cap_pend || !pend)) return PTAMD_OK;
+int ensure_buffers(ptamd_context *c, int64_t paths, int nls, bool pend, bool dup) {
+  if (c->slab && c->cap_paths >= paths && c->cap_nls >= nls && (c->cap_pend || !pend) && (c->cap_dup || !dup)) return PTAMD_OK;
   if (c->slab) {
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipFree(c->slab));
@@ -231,14 +240,23 @@ int ensure_buffers(ptamd_context *c, int64_t paths, int nls, bool pend) {
   paths = std::max<int64_t>(paths, c->cap_paths);
   nls = std::max(nls, std::max(c->cap_nls, 1));
   pend = pend || c->cap_pend;
+  dup = dup || c->cap_dup;
   const size_t P = (size_t)paths, PN = P * (size_t)nls;
   auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
   size_t total = 0;
   auto take = [&](size_t bytes) { size_t o = total; total += al(bytes); return o; };
-  size_t off_q[2][10], off_hit[4], off_sq[5], off_vb[8], off_pb[6], off_list[2], off_cp[3], off_nee[4], off_map[5];
-  for (int k = 0; k < 2; k++) {
+  size_t off_dup[5] = {0, 0, 0, 0, 0};
+  size_t off_q[3][10], off_hit[4], off_sq[5], off_vb[8], off_pb[6], off_list[2], off_cp[3], off_nee[4], off_map[5];
+  for (int k = 0; k < (dup ? 3 : 2); k++) {
     off_q[k][0] = take(P * 4);
     for (int j = 1; j < 10; j++) off_q[k][j] = take(P * 8);
+  }
+  if (dup) {
+    off_dup[0] = take(P);
+    off_dup[1] = take(PN * sizeof(Contrib));
+    off_dup[2] = take(PN + 4);
+    off_dup[3] = take(PN * 4);
+    off_dup[4] = take(PN * sizeof(SRay));
   }
   off_hit[0] = take(P * 4);
   off_hit[1] = take(P * 8);
@@ -264,7 +282,7 @@ int ensure_buffers(ptamd_context *c, int64_t paths, int nls, bool pend) {
   off_cp[2] = take((P / 256 + 2) * 4);
   HIPCHK(hipMalloc(&c->slab, total));
   char *b = (char *)c->slab;
-  for (int k = 0; k < 2; k++) {
+  for (int k = 0; k < (dup ? 3 : 2); k++) {
     c->q[k].path = (int32_t *)(b + off_q[k][0]);
     for (int j = 0; j < 3; j++) {
       c->q[k].o[j] = (double *)(b + off_q[k][1 + j]);
@@ -299,7 +317,16 @@ int ensure_buffers(ptamd_context *c, int64_t paths, int nls, bool pend) {
   c->cp.cnt_shadow = (uint32_t *)(b + off_cp[2]);
   c->cap_paths = paths;
   c->cap_nls = nls;
+  c->flag_p[0] = c->vb.flag; c->contrib_p[0] = c->vb.contrib; c->vis_p[0] = c->vb.vis; c->pend_prim_p[0] = c->vb.pend_prim; c->ray_p[0] = c->sq.ray;
+  if (dup) {
+    c->flag_p[1] = (uint8_t *)(b + off_dup[0]);
+    c->contrib_p[1] = (Contrib *)(b + off_dup[1]);
+    c->vis_p[1] = (uint8_t *)(b + off_dup[2]);
+    c->pend_prim_p[1] = (int32_t *)(b + off_dup[3]);
+    c->ray_p[1] = (SRay *)(b + off_dup[4]);
+  }
   c->cap_pend = true;
+  c->cap_dup = dup;
   return PTAMD_OK;
 }
 
@@ -356,6 +383,7 @@ int ptamd_create(int32_t device_id, ptamd_context **out) {
   if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) c->num_cu = prop.multiProcessorCount;
   if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) c->own_stream = nullptr;
   if (const char *e = getenv("PTAMD_TRACE_TWO")) c->trace_two = atoi(e) != 0;
+  if (const char *e = getenv("PTAMD_FUSE_RESOLVE")) c->fuse_resolve = atoi(e) != 0;
   if (const char *e = getenv("PTAMD_FUSE_BELOW")) c->fuse_below = (uint32_t)strtoul(e, nullptr, 10);
   if (const char *e = getenv("PTAMD_PREDICT_ABOVE")) c->predict_above = std::max<long long>(0, atoll(e));
   if (const char *e = getenv("PTAMD_PLAN_MARGIN")) { const double m = atof(e); if (m >= 1.0 && m <= 8.0) c->plan_margin = m; }
@@ -588,13 +616,18 @@ int ptamd_trace_list(ptamd_context *c, const ptamd_pixel_list *list, int32_t sam
   }
   const FastDiv by_nls = make_fastdiv((uint32_t)nls);
   const uint2 nls_nsa = make_uint2((uint32_t)nls, (uint32_t)std::max(fp.ns_area_light, 0));  // light samples per vertex, per area light
+  // A depth's light samples are settled beside the next depth's light sampling (k_light_resolve) where the shading
+  // kernel of that next depth leaves the paths' sums alone: bounces accumulated (-o 1, else k_shade hands `pending`
+  // on), no delta materials, importance sampling.
+  const bool overlap = c->fuse_resolve && fp.accum && !fp.specular && !fp.hemisphere && fp.max_ray_depth > 1 && fp.nls > 0;
   // paths per launch: max_paths, but never more than a 24 GB slab of work buffers
-  // (about 290 bytes per path + 70 per light-sample slot), and never so many that a light-sample
-  // slot index (entry * nls + q, an int32) would pass 2^31
-  const int64_t by_memory = std::min(((int64_t)24 << 30) / (290 + 70 * (int64_t)nls), (((int64_t)1 << 31) - 1) / nls);
+  // (about 290 bytes per path + 70 per light-sample slot; 40 GB, 370 and 131 with the per-depth copies),
+  // and never so many that a light-sample slot index (entry * nls + q, an int32) would pass 2^31
+  const int64_t by_memory = std::min(overlap ? ((int64_t)40 << 30) / (370 + 131 * (int64_t)nls) : ((int64_t)24 << 30) / (290 + 70 * (int64_t)nls),
+                                     (((int64_t)1 << 31) - 1) / nls);
   int64_t px_per_chunk = std::max<int64_t>(1, std::min(c->max_paths, by_memory) / n_samples);
   px_per_chunk = std::min(px_per_chunk, n);
-  rc = ensure_buffers(c, px_per_chunk * n_samples, nls, !fp.accum);
+  rc = ensure_buffers(c, px_per_chunk * n_samples, nls, !fp.accum, overlap);
   if (rc) return rc;
   TravLaunch tl;
   rc = traversal_launch(c, &tl);
@@ -635,39 +668,49 @@ int ptamd_trace_list(ptamd_context *c, const ptamd_pixel_list *list, int32_t sam
     }
     hipLaunchKernelGGL(k_generate, ggrid, 256, 0, s, fp, c->S, pv, up0, c->ctl, rp, pm, c->q[0], pb);
     L.end();
-    int cur = 0;
+    int cur = 0;   // list[cur]: this depth's list, list[cur ^ 1]: the next one's
+    int qi = 0;    // q[qi]: this depth's rays, q[qo]: the next depth's (its origin arrays hold this depth's hit points)
+    const int nq = overlap ? 3 : 2;
+    ResolveArgs prev{};  // the depth whose light samples have been traced but not yet summed (overlap)
     bool traced_ahead = false;  // this depth's bounce rays went with the previous depth's shadow rays (k_trace2)
     for (int depth = 1; depth <= depths; depth++) {
+      const int qo = (qi + 1) % nq, par = overlap ? (depth & 1) : 0;
       const double min_t = depth == 1 ? fp.n_clip : PT_EPS_D;
       const double max_t = depth == 1 ? fp.f_clip : (double)INFINITY;
       const int32_t *lst = depth == 1 ? nullptr : c->list[cur];
       if (!traced_ahead) {
         L.begin(PTAMD_K_EXTEND);
         PTAMD_WAVELOG_NEXT(c, 0, egrid);
-        if (c->prof_counters) hipLaunchKernelGGL((k_extend<true>), egrid, tblock, elds, s, c->S, c->q[cur], lst, c->hb, c->ctl, min_t, max_t, gstack, (const int32_t *)c->vb.self_code, (const float *)c->vb.self_dmin);
-        else hipLaunchKernelGGL((k_extend<false>), egrid, tblock, elds, s, c->S, c->q[cur], lst, c->hb, c->ctl, min_t, max_t, gstack, (const int32_t *)c->vb.self_code, (const float *)c->vb.self_dmin);
+        if (c->prof_counters) hipLaunchKernelGGL((k_extend<true>), egrid, tblock, elds, s, c->S, c->q[qi], lst, c->hb, c->ctl, min_t, max_t, gstack, (const int32_t *)c->vb.self_code, (const float *)c->vb.self_dmin);
+        else hipLaunchKernelGGL((k_extend<false>), egrid, tblock, elds, s, c->S, c->q[qi], lst, c->hb, c->ctl, min_t, max_t, gstack, (const int32_t *)c->vb.self_code, (const float *)c->vb.self_dmin);
         L.end();
       }
       traced_ahead = false;
       VertexBuf vb = c->vb;
-      for (int k = 0; k < 3; k++) vb.hp[k] = c->q[cur ^ 1].o[k];  // one copy of the hit point serves both uses
+      for (int k = 0; k < 3; k++) vb.hp[k] = c->q[qo].o[k];  // one copy of the hit point serves both uses
+      vb.flag = c->flag_p[par]; vb.contrib = c->contrib_p[par]; vb.vis = c->vis_p[par]; vb.pend_prim = c->pend_prim_p[par];
+      ShadowQ sq = c->sq;
+      sq.ray = c->ray_p[par];
       L.begin(PTAMD_K_SHADE);
       if (fp.hemisphere)
-        hipLaunchKernelGGL(k_shade<true>, shade_grid, 256, 0, s, fp, c->S, c->q[cur], lst, c->hb, c->q[cur ^ 1], c->sq, vb, pb,
+        hipLaunchKernelGGL(k_shade<true>, shade_grid, 256, 0, s, fp, c->S, c->q[qi], lst, c->hb, c->q[qo], sq, vb, pb,
                            c->cp, c->ctl, depth);
       else
-        hipLaunchKernelGGL(k_shade<false>, shade_grid, 256, 0, s, fp, c->S, c->q[cur], lst, c->hb, c->q[cur ^ 1], c->sq, vb, pb,
+        hipLaunchKernelGGL(k_shade<false>, shade_grid, 256, 0, s, fp, c->S, c->q[qi], lst, c->hb, c->q[qo], sq, vb, pb,
                            c->cp, c->ctl, depth);
       L.end();
       if (!fp.hemisphere && fp.max_ray_depth > 0 && fp.nls > 0) {
         L.begin(PTAMD_K_LIGHT);
-        hipLaunchKernelGGL(k_light, PTAMD_LIGHT_LOOP ? std::min(light_grid, grid_for(c, PTAMD_LIGHT_LOOP)) : light_grid, 256, 0, s, fp, c->S, vb, c->sq, c->cp, c->ctl, by_nls,
-                           1u + (uint32_t)(depth - 1) * (uint32_t)fp.bpv);
+        const uint32_t rng_base = 1u + (uint32_t)(depth - 1) * (uint32_t)fp.bpv;
+        if (overlap && depth > 1)  // with the previous depth's k_resolve: at most light_grid + shade_grid workgroups have work
+          hipLaunchKernelGGL(k_light_resolve, light_grid + shade_grid, 256, 0, s, fp, c->S, vb, sq, c->cp, c->ctl, by_nls, rng_base, prev);
+        else
+          hipLaunchKernelGGL(k_light, light_grid, 256, 0, s, fp, c->S, vb, sq, c->cp, c->ctl, by_nls, rng_base);
         L.end();
       }
       L.begin(PTAMD_K_OTHER);
       hipLaunchKernelGGL(k_scan2, 1, 1024, 0, s, c->cp, c->ctl);
-      hipLaunchKernelGGL(k_scatter, ggrid, 256, 0, s, c->cp, vb, c->list[cur ^ 1], c->sq, c->ctl, fp.max_ray_depth > 0 ? fp.nls : 0);
+      hipLaunchKernelGGL(k_scatter, ggrid, 256, 0, s, c->cp, vb, c->list[cur ^ 1], sq, c->ctl, fp.max_ray_depth > 0 ? fp.nls : 0);
       L.end();
       if (fp.max_ray_depth > 0 && fp.nls > 0) {
         uint32_t shadow_skip = 0;  // k_shadow skips lists that k_trace2 has traced: those shorter than this
@@ -677,7 +720,7 @@ int ptamd_trace_list(ptamd_context *c, const ptamd_pixel_list *list, int32_t sam
           L.begin(PTAMD_K_TRACE2);
           PTAMD_WAVELOG_NEXT(c, 1, egrid);
           const bool hemi = fp.hemisphere != 0, cnt = c->prof_counters;
-#define PTAMD_LAUNCH_TRACE2(H, C) hipLaunchKernelGGL((k_trace2<H, C>), egrid, tblock, elds, s, c->S, c->q[cur ^ 1], (const int32_t *)c->list[cur ^ 1], c->hb, c->sq, vb, c->ctl, by_nls, nls_nsa, gstack, c->fuse_below)
+#define PTAMD_LAUNCH_TRACE2(H, C) hipLaunchKernelGGL((k_trace2<H, C>), egrid, tblock, elds, s, c->S, c->q[qo], (const int32_t *)c->list[cur ^ 1], c->hb, sq, vb, c->ctl, by_nls, nls_nsa, gstack, c->fuse_below)
           if (hemi) { if (cnt) PTAMD_LAUNCH_TRACE2(true, true); else PTAMD_LAUNCH_TRACE2(true, false); }
           else { if (cnt) PTAMD_LAUNCH_TRACE2(false, true); else PTAMD_LAUNCH_TRACE2(false, false); }
 #undef PTAMD_LAUNCH_TRACE2
@@ -693,24 +736,33 @@ int ptamd_trace_list(ptamd_context *c, const ptamd_pixel_list *list, int32_t sam
           L.begin(PTAMD_K_SHADOW);
           PTAMD_WAVELOG_NEXT(c, 2, sgrid);
           if (fp.hemisphere) {
-            if (c->prof_counters) hipLaunchKernelGGL((k_shadow<true, true>), sgrid, tblock, slds, s, c->S, c->sq, vb, c->ctl, by_nls, nls_nsa, gstack, shadow_skip);
-            else hipLaunchKernelGGL((k_shadow<true, false>), sgrid, tblock, slds, s, c->S, c->sq, vb, c->ctl, by_nls, nls_nsa, gstack, shadow_skip);
+            if (c->prof_counters) hipLaunchKernelGGL((k_shadow<true, true>), sgrid, tblock, slds, s, c->S, sq, vb, c->ctl, by_nls, nls_nsa, gstack, shadow_skip);
+            else hipLaunchKernelGGL((k_shadow<true, false>), sgrid, tblock, slds, s, c->S, sq, vb, c->ctl, by_nls, nls_nsa, gstack, shadow_skip);
           } else {
-            if (c->prof_counters) hipLaunchKernelGGL((k_shadow<false, true>), sgrid, tblock, slds, s, c->S, c->sq, vb, c->ctl, by_nls, nls_nsa, gstack, shadow_skip);
-            else hipLaunchKernelGGL((k_shadow<false, false>), sgrid, tblock, slds, s, c->S, c->sq, vb, c->ctl, by_nls, nls_nsa, gstack, shadow_skip);
+            if (c->prof_counters) hipLaunchKernelGGL((k_shadow<false, true>), sgrid, tblock, slds, s, c->S, sq, vb, c->ctl, by_nls, nls_nsa, gstack, shadow_skip);
+            else hipLaunchKernelGGL((k_shadow<false, false>), sgrid, tblock, slds, s, c->S, sq, vb, c->ctl, by_nls, nls_nsa, gstack, shadow_skip);
           }
           L.end();
         }
-        L.begin(PTAMD_K_RESOLVE);
-        hipLaunchKernelGGL(k_resolve, shade_grid, 256, 0, s, fp, c->S, c->q[cur], lst, vb, (const SRay *)c->sq.ray, pb, c->ctl, depth);
-        hipLaunchKernelGGL(k_advance, 1, 1, 0, s, c->ctl);
-        L.end();
+        if (overlap && depth < depths) {
+          // summed by the next depth's k_light_resolve
+          prev = ResolveArgs{c->q[qi], lst, vb, (const SRay *)sq.ray, pb, depth};
+          L.begin(PTAMD_K_OTHER);
+          hipLaunchKernelGGL(k_advance, 1, 1, 0, s, c->ctl);
+          L.end();
+        } else {
+          L.begin(PTAMD_K_RESOLVE);
+          hipLaunchKernelGGL(k_resolve, shade_grid, 256, 0, s, fp, c->S, c->q[qi], lst, vb, (const SRay *)sq.ray, pb, c->ctl, depth);
+          hipLaunchKernelGGL(k_advance, 1, 1, 0, s, c->ctl);
+          L.end();
+        }
       } else {
         L.begin(PTAMD_K_OTHER);
         hipLaunchKernelGGL(k_advance, 1, 1, 0, s, c->ctl);
         L.end();
       }
       cur ^= 1;
+      qi = qo;
     }
     L.begin(PTAMD_K_ACCUMULATE);
     hipLaunchKernelGGL(k_accumulate, ggrid, 256, 0, s, pv, up0, c->ctl, rp, pm, pb, d_state);
@@ -1006,7 +1058,7 @@ int ptamd_trace_primary(ptamd_context *c, int64_t n, const double *sx, const dou
   if (rc) return rc;
   HIPCHK(hipSetDevice(c->device));
   const int64_t chunk = std::min<int64_t>(std::max<int64_t>(n, 1), c->max_paths);
-  rc = ensure_buffers(c, chunk, std::max(c->cap_nls, 1), false);
+  rc = ensure_buffers(c, chunk, std::max(c->cap_nls, 1), false, false);
   if (rc) return rc;
   TravLaunch tl;
   rc = traversal_launch(c, &tl);

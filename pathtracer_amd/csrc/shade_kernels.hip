@@ -103,6 +103,7 @@ __global__ void k_plan_offsets(PixView pv, uint32_t p0, Ctl *ctl, RoundPlan rp, 
 __global__ void k_advance(Ctl *ctl) {
   ctl->st_rays += (unsigned long long)ctl->n_cur + ctl->n_shadow;
   ctl->st_shadow += ctl->n_shadow;
+  ctl->n_prev = ctl->n_cur;
   ctl->n_cur = ctl->n_next;
   ctl->n_next = 0;
   ctl->n_shadow = 0;
@@ -464,26 +465,13 @@ __global__ void __launch_bounds__(256)
 // records, the visibility byte; per workgroup the number of shadow rays, added to the count of its
 // 256-entry block for the compaction (an integer sum: the same on every run).
 // Split off k_shade, where one lane ran the whole light loop of its vertex at 131 registers.
-#ifndef PTAMD_LIGHT_WAVES
-#define PTAMD_LIGHT_WAVES 0  // waves per SIMD k_light is compiled for (0: the compiler's choice)
-#endif
-#if PTAMD_LIGHT_WAVES
-#define LIGHT_BOUNDS __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PTAMD_LIGHT_WAVES, PTAMD_LIGHT_WAVES)))
-#else
-#define LIGHT_BOUNDS __launch_bounds__(256)
-#endif
-__global__ void LIGHT_BOUNDS
-    k_light(FrameParams fp, DevScene S, VertexBuf vb, ShadowQ sq, Compact cp, Ctl *ctl, FastDiv by_nls, uint32_t rng_base) {
+// (one workgroup per 256 slots, `blk` its number)
+__device__ __forceinline__ void light_block(uint32_t blk, const FrameParams &fp, const DevScene &S, const VertexBuf &vb, const ShadowQ &sq,
+                                            const Compact &cp, Ctl *ctl, const FastDiv &by_nls, uint32_t rng_base) {
   __shared__ uint32_t wsum[4];
   const uint32_t n = ctl->n_cur;
   const uint32_t nls = (uint32_t)fp.nls;
   const uint32_t n_slots = n * nls;  // < 2^31 (ptamd_trace_list)
-#if PTAMD_LIGHT_LOOP
-  for (uint32_t blk = blockIdx.x; blk * 256u < n_slots; blk += gridDim.x) {
-#else
-  const uint32_t blk = blockIdx.x;
-  {
-#endif
   const uint32_t slot0 = blk * 256u;
   if (slot0 >= n_slots) return;
   const uint32_t slot = slot0 + threadIdx.x;
@@ -573,10 +561,11 @@ __global__ void LIGHT_BOUNDS
     // 256 consecutive slots from a multiple of 256 lie inside one block of 256 entries x nls slots
     if (t) atomicAdd(&cp.cnt_shadow[blk / nls], t);
   }
-#if PTAMD_LIGHT_LOOP
-  __syncthreads();
-#endif
-  }
+}
+
+__global__ void __launch_bounds__(256)
+    k_light(FrameParams fp, DevScene S, VertexBuf vb, ShadowQ sq, Compact cp, Ctl *ctl, FastDiv by_nls, uint32_t rng_base) {
+  light_block(blockIdx.x, fp, S, vb, sq, cp, ctl, by_nls, rng_base);
 }
 
 // Exclusive scan of the two per-block count arrays (one workgroup); the totals
@@ -703,13 +692,14 @@ __device__ __forceinline__ bool pending_visible(const DevScene &S, const VertexB
                              PT_EPS_D, t, u, v);
   return !(ok && t < r.max_t);
 }
-__global__ void k_resolve(FrameParams fp, DevScene S, RayQ q, const int32_t *__restrict__ list, VertexBuf vb,
-                          const SRay *__restrict__ rays, PathBuf pb, Ctl *ctl, int32_t depth) {
-  const uint32_t n = ctl->n_cur;
+// (one workgroup per 256 entries, as k_shade; `blk` its number, n the length of the list)
+__device__ __forceinline__ void resolve_block(uint32_t blk, uint32_t n, const FrameParams &fp, const DevScene &S, const RayQ &q,
+                                              const int32_t *__restrict__ list, const VertexBuf &vb, const SRay *__restrict__ rays,
+                                              const PathBuf &pb, Ctl *ctl, int32_t depth) {
   const int nls = fp.nls;
   unsigned long long verts = 0;
-  {  // one workgroup per 256 entries, as k_shade
-    const uint32_t base_i = blockIdx.x * blockDim.x;
+  {
+    const uint32_t base_i = blk * blockDim.x;
     if (base_i >= n) return;
     const uint32_t i = base_i + threadIdx.x;
     if (i < n) {
@@ -772,6 +762,29 @@ __global__ void k_resolve(FrameParams fp, DevScene S, RayQ q, const int32_t *__r
     }
   }
   block_add(&ctl->st_vertices, verts);
+}
+__global__ void k_resolve(FrameParams fp, DevScene S, RayQ q, const int32_t *__restrict__ list, VertexBuf vb,
+                          const SRay *__restrict__ rays, PathBuf pb, Ctl *ctl, int32_t depth) {
+  resolve_block(blockIdx.x, ctl->n_cur, fp, S, q, list, vb, rays, pb, ctl, depth);
+}
+// k_light of depth d + 1 and k_resolve of depth d in ONE launch: the first is bound by instruction issue,
+// the second by its memory round trips, and they touch different records once the per-sample records, the
+// vertex flags and the ray queues are kept per depth (ptamd_trace_list). Launched on two streams the two
+// kernels ran one after the other; as workgroups of one grid they share the compute units. Every workgroup
+// takes one role; the resolve workgroups are spread evenly among the light workgroups (of the first L + R
+// workgroups, L light and R resolve, workgroup b resolves iff floor((b + 1) R / (L + R)) > floor(b R / (L + R))),
+// so that both kinds are resident throughout the launch. `prev`: the list, the queue, the vertex and sample
+// records of depth d, whose length k_advance has kept in Ctl::n_prev.
+__global__ void __launch_bounds__(256)
+    k_light_resolve(FrameParams fp, DevScene S, VertexBuf vb, ShadowQ sq, Compact cp, Ctl *ctl, FastDiv by_nls, uint32_t rng_base,
+                    ResolveArgs prev) {
+  const uint32_t n_prev = ctl->n_prev;
+  const unsigned long long L = ((unsigned long long)ctl->n_cur * (uint32_t)fp.nls + 255u) >> 8, R = (n_prev + 255u) >> 8;
+  const unsigned long long b = blockIdx.x, total = L + R;
+  if (b >= total) return;
+  const unsigned long long r_before = b * R / total;
+  if ((b + 1) * R / total > r_before) resolve_block((uint32_t)r_before, n_prev, fp, S, prev.q, prev.list, prev.vb, prev.rays, prev.pb, ctl, prev.depth);
+  else light_block((uint32_t)(b - r_before), fp, S, vb, sq, cp, ctl, by_nls, rng_base);
 }
 // Folds the round's finished paths into the per-pixel sums, in sample order:
 // the loop of raytrace_pixel (pathtracer.cpp:249-267) over radiances that are

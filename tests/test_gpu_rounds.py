@@ -150,7 +150,7 @@ def test_list_argument_errors(device):
 
 # (both tests below look at the default launch policy; a run that overrides it through the
 # environment, as the A/B scripts do, has nothing to check here)
-_POLICY_OVERRIDDEN = any(k in os.environ for k in ("PTAMD_FUSE_BELOW", "PTAMD_TRACE_TWO"))
+_POLICY_OVERRIDDEN = any(k in os.environ for k in ("PTAMD_FUSE_BELOW", "PTAMD_TRACE_TWO", "PTAMD_FUSE_RESOLVE"))
 
 
 @pytest.mark.skipif(_POLICY_OVERRIDDEN, reason="launch policy overridden in the environment")
@@ -189,6 +189,44 @@ def test_fused_and_separate_traversal_launches_give_the_same_frame(device, monke
     finally:
         other.close()
     assert np.array_equal(cnt_f, cnt_s) and np.array_equal(hdr_f, hdr_s)
+
+
+@pytest.mark.skipif(_POLICY_OVERRIDDEN, reason="launch policy overridden in the environment")
+def test_light_samples_settled_beside_the_next_depth_give_the_same_frame(device, monkeypatch):
+    """k_light_resolve (a depth's light samples summed by workgroups of the launch that draws the next
+    depth's samples, with the records the two share kept per depth) against k_light and k_resolve one
+    after the other (PTAMD_FUSE_RESOLVE=0, read when a context is created): same frame, same counts, and
+    the modes that cannot use it (bounces not accumulated, specular materials, hemisphere sampling) still
+    launch k_resolve once per depth."""
+    sc = pt.Scene(scene_path("CBbunny"))
+    device.upload(sc)
+    device.set_camera(sc.camera(W, H))
+    monkeypatch.setenv("PTAMD_FUSE_RESOLVE", "0")
+    other = pt.Device(0)
+    try:
+        other.upload(sc)
+        other.set_camera(sc.camera(W, H))
+        for kw in (dict(ns_aa=64, max_ray_depth=5, ns_area_light=4, seed=11), dict(ns_aa=32, max_ray_depth=2, ns_area_light=3, seed=2),
+                   dict(ns_aa=32, max_ray_depth=7, ns_area_light=1, seed=4)):
+            p = cabi.make_params(W, H, **kw)
+            hdr_f, cnt_f = device.render(p)
+            st_f = device.stats()
+            hdr_s, cnt_s = other.render(p)
+            st_s = other.stats()
+            assert np.array_equal(cnt_f, cnt_s) and np.array_equal(hdr_f, hdr_s), repr(kw)
+            assert (st_f.rays, st_f.shadow_rays, st_f.samples, st_f.path_vertices) == (st_s.rays, st_s.shadow_rays, st_s.samples, st_s.path_vertices)
+            # one k_resolve per round is left (the last depth's), the others ride with k_light
+            assert st_f.launches[cabi.K_RESOLVE] * kw["max_ray_depth"] == st_s.launches[cabi.K_RESOLVE] > 0, repr(kw)
+            assert st_f.launches[cabi.K_LIGHT] == st_s.launches[cabi.K_LIGHT]
+        for kw in (dict(accumulate_bounces=False), dict(hemisphere=True), dict(specular=True), dict(max_ray_depth=1)):
+            p = cabi.make_params(W, H, **{**dict(ns_aa=32, max_ray_depth=3, ns_area_light=2, seed=3), **kw})
+            hdr_f, cnt_f = device.render(p)
+            st_f = device.stats()
+            hdr_s, cnt_s = other.render(p)
+            assert np.array_equal(cnt_f, cnt_s) and np.array_equal(hdr_f, hdr_s), repr(kw)
+            assert st_f.launches[cabi.K_RESOLVE] == other.stats().launches[cabi.K_RESOLVE], repr(kw)
+    finally:
+        other.close()
 
 
 @pytest.mark.skipif(_POLICY_OVERRIDDEN, reason="launch policy overridden in the environment")

@@ -97,7 +97,7 @@ def main():
     ap.add_argument("--src", nargs="*", default=[os.path.join(csrc, u) for u in ("trace_kernels.hip", "shade_kernels.hip")])
     ap.add_argument("--asm", nargs="*", default=None, help="existing gfx950 .s files instead of compiling")
     ap.add_argument("--json", default=None)
-    ap.add_argument("names", nargs="*", default=["k_trace2ILb0ELb0", "k_shadowILb0ELb0", "k_extendILb0", "k_shadeILb0", "k_light", "k_resolve"])
+    ap.add_argument("names", nargs="*", default=["k_trace2ILb0ELb0", "k_shadowILb0ELb0", "k_extendILb0", "k_shadeILb0", "k_light_resolve", "k_lightE", "k_resolve"])
     a = ap.parse_args()
     ks = {}
     for f in (a.asm or [compile_asm(u) for u in a.src]):

@@ -66,7 +66,7 @@ def main():
     print("kernel              calls   total_ms   avg_us    pct")
     for k, v in sorted(res["kernels"].items(), key=lambda kv: -kv[1]["total_ms"])[:12]:
         print("%-34s %6d %10.2f %9.1f %6.2f" % (k, v["calls"], v["total_ms"], v["avg_us"], v["pct"]))
-    for k in ("k_shadow<false, false>", "k_trace2<false, false>", "k_extend<false>", "k_shade<false>", "k_light", "k_resolve"):
+    for k in ("k_shadow<false, false>", "k_trace2<false, false>", "k_extend<false>", "k_shade<false>", "k_light_resolve", "k_light", "k_resolve"):
         row = {}
         for p in ("pmc_fetch", "pmc_write", "pmc_l2", "pmc_sq", "pmc_grbm", "pmc_sq2", "pmc_l1"):
             row.update({c: v for c, v in res[p].get(k, {}).items() if not c.startswith("_")})

@@ -187,7 +187,8 @@ void ptamd_destroy(ptamd_context *ctx);
 int ptamd_upload_scene(ptamd_context *ctx, const ptamd_scene_desc *desc);
 /* Replaces RaytracedRenderer::set_camera (raytraced_renderer.cpp:136-149). */
 int ptamd_set_camera(ptamd_context *ctx, const ptamd_camera *cam);
-/* Bound on paths in flight per wavefront pass (0 = default). */
+/* Bound on paths in flight per wavefront pass (0 = default, 16 Mi). The work buffers are sized by it:
+ * up to 370 + 131 x light samples per vertex bytes per path (about 15 GB at the default and -l 4). */
 int ptamd_set_max_paths(ptamd_context *ctx, int64_t max_paths);
 /* Enables per-launch HIP-event timing and traversal counters (slower). */
 int ptamd_set_profiling(ptamd_context *ctx, int32_t events, int32_t counters);

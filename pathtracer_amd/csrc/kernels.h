@@ -11,7 +11,7 @@ namespace ptk {
 // ---- trace_kernels.hip
 template <bool COUNT>
 __global__ void k_extend(DevScene S, RayQ q, const int32_t *__restrict__ list, HitBuf hb, Ctl *ctl, double min_t, double max_t,
-                         uint2 *gstack, const int32_t *__restrict__ self_code, const float *__restrict__ self_dmin);
+                         uint2 *gstack, const int32_t *__restrict__ self_code, const float *__restrict__ self_dmin, v3 cam_o);
 template <bool HEMI, bool COUNT>
 __global__ void k_shadow(DevScene S, ShadowQ sq, VertexBuf vb, Ctl *ctl, FastDiv by_nls, uint2 nls_nsa, uint2 *gstack, uint32_t fuse_below);
 template <bool HEMI, bool COUNT>
@@ -27,7 +27,7 @@ __global__ void k_plan_offsets(PixView pv, uint32_t p0, Ctl *ctl, RoundPlan rp, 
                                uint32_t *__restrict__ off, uint32_t *__restrict__ slot_pix);
 __global__ void k_generate(FrameParams fp, DevScene S, PixView pv, uint32_t p0, Ctl *ctl, RoundPlan rp, PathMap pm, RayQ q, PathBuf pb);
 __global__ void k_generate_primary(FrameParams fp, const double *__restrict__ sx, const double *__restrict__ sy, uint32_t n, RayQ q);
-__global__ void k_primary_t(DevScene S, RayQ q, const int32_t *__restrict__ prim, uint32_t n, double min_t, double *__restrict__ t_out);
+__global__ void k_primary_t(DevScene S, RayQ q, const int32_t *__restrict__ prim, uint32_t n, double min_t, double *__restrict__ t_out, v3 cam_o);
 template <bool HEMI>
 __global__ void k_shade(FrameParams fp, DevScene S, RayQ q, const int32_t *__restrict__ list, HitBuf hb, RayQ qn, ShadowQ sq,
                         VertexBuf vb, PathBuf pb, Compact cp, Ctl *ctl, int32_t depth);

@@ -681,8 +681,8 @@ int ptamd_trace_list(ptamd_context *c, const ptamd_pixel_list *list, int32_t sam
       if (!traced_ahead) {
         L.begin(PTAMD_K_EXTEND);
         PTAMD_WAVELOG_NEXT(c, 0, egrid);
-        if (c->prof_counters) hipLaunchKernelGGL((k_extend<true>), egrid, tblock, elds, s, c->S, c->q[qi], lst, c->hb, c->ctl, min_t, max_t, gstack, (const int32_t *)c->vb.self_code, (const float *)c->vb.self_dmin);
-        else hipLaunchKernelGGL((k_extend<false>), egrid, tblock, elds, s, c->S, c->q[qi], lst, c->hb, c->ctl, min_t, max_t, gstack, (const int32_t *)c->vb.self_code, (const float *)c->vb.self_dmin);
+        if (c->prof_counters) hipLaunchKernelGGL((k_extend<true>), egrid, tblock, elds, s, c->S, c->q[qi], lst, c->hb, c->ctl, min_t, max_t, gstack, (const int32_t *)c->vb.self_code, (const float *)c->vb.self_dmin, fp.cam_pos);
+        else hipLaunchKernelGGL((k_extend<false>), egrid, tblock, elds, s, c->S, c->q[qi], lst, c->hb, c->ctl, min_t, max_t, gstack, (const int32_t *)c->vb.self_code, (const float *)c->vb.self_dmin, fp.cam_pos);
         L.end();
       }
       traced_ahead = false;
@@ -1075,8 +1075,8 @@ int ptamd_trace_primary(ptamd_context *c, int64_t n, const double *sx, const dou
     HIPCHK(hipMemcpyAsync(d_sy, sy + b, m * sizeof(double), hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_set_counts, 1, 1, 0, s, c->ctl, PixView{nullptr, nullptr, (long long)m, 0u, 1u}, 0u, (uint32_t)m, 1u);
     hipLaunchKernelGGL(k_generate_primary, grid_for(c, 4), 256, 0, s, fp, d_sx, d_sy, (uint32_t)m, c->q[0]);
-    hipLaunchKernelGGL((k_extend<false>), tgrid, tblock, lds, s, c->S, c->q[0], (const int32_t *)nullptr, c->hb, c->ctl, fp.n_clip, fp.f_clip, tl.gstack, (const int32_t *)nullptr, (const float *)nullptr);
-    hipLaunchKernelGGL(k_primary_t, grid_for(c, 4), 256, 0, s, c->S, c->q[0], (const int32_t *)c->hb.prim, (uint32_t)m, fp.n_clip, c->hb.t);
+    hipLaunchKernelGGL((k_extend<false>), tgrid, tblock, lds, s, c->S, c->q[0], (const int32_t *)nullptr, c->hb, c->ctl, fp.n_clip, fp.f_clip, tl.gstack, (const int32_t *)nullptr, (const float *)nullptr, fp.cam_pos);
+    hipLaunchKernelGGL(k_primary_t, grid_for(c, 4), 256, 0, s, c->S, c->q[0], (const int32_t *)c->hb.prim, (uint32_t)m, fp.n_clip, c->hb.t, fp.cam_pos);
     HIPCHK(hipMemcpyAsync(prim.data(), c->hb.prim, m * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(t_out + b, c->hb.t, m * sizeof(double), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));

@@ -153,7 +153,8 @@ __global__ void k_generate(FrameParams fp, DevScene S, PixView pv, uint32_t p0, 
     const double sxp = (double)x + js[0], syp = (double)y + js[1];
     v3 o, d;
     camera_ray(fp, sxp / (double)fp.w, syp / (double)fp.h, o, d);
-    q.o[0][k] = o.x; q.o[1][k] = o.y; q.o[2][k] = o.z;
+    // (every camera ray starts at fp.cam_pos: the kernels that read a camera ray take its origin from there,
+    // and the 24 bytes per path are neither written nor read)
     q.d[0][k] = d.x; q.d[1][k] = d.y; q.d[2][k] = d.z;
   }
   block_add(&ctl->st_dead, dead);
@@ -167,7 +168,6 @@ __global__ void k_generate_primary(FrameParams fp, const double *__restrict__ sx
     v3 o, d;
     camera_ray(fp, sx[k], sy[k], o, d);
     q.path[k] = (int32_t)k;
-    q.o[0][k] = o.x; q.o[1][k] = o.y; q.o[2][k] = o.z;
     q.d[0][k] = d.x; q.d[1][k] = d.y; q.d[2][k] = d.z;
   }
 }
@@ -175,12 +175,12 @@ __global__ void k_generate_primary(FrameParams fp, const double *__restrict__ sx
 // hit distances of traced camera rays (ptamd_trace_primary): the walk names the primitive, the
 // reference's test gives its t
 __global__ void k_primary_t(DevScene S, RayQ q, const int32_t *__restrict__ prim, uint32_t n, double min_t,
-                            double *__restrict__ t_out) {
+                            double *__restrict__ t_out, v3 cam_o) {
   const uint32_t stride = gridDim.x * blockDim.x;
   for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) {
     double t = -1.0, u, v;
     if (prim[k] >= 0)
-      exact_test(S, prim[k], V(q.o[0][k], q.o[1][k], q.o[2][k]), V(q.d[0][k], q.d[1][k], q.d[2][k]), min_t, t, u, v);
+      exact_test(S, prim[k], cam_o, V(q.d[0][k], q.d[1][k], q.d[2][k]), min_t, t, u, v);
     t_out[k] = t;
   }
 }
@@ -301,7 +301,7 @@ __global__ void __launch_bounds__(256)
         const int32_t mat = info >> 1;
         nee_mat = mat;
         const int32_t kind = S.mat_kind[mat];
-        const v3 ro = V(q.o[0][j], q.o[1][j], q.o[2][j]);
+        const v3 ro = depth == 1 ? fp.cam_pos : V(q.o[0][j], q.o[1][j], q.o[2][j]);  // (camera rays: see k_generate)
         const v3 rd = V(q.d[0][j], q.d[1][j], q.d[2][j]);
         // the walk only names the primitive: its t, u, v as the reference computes them
         double t, u, v;

@@ -19,6 +19,7 @@ struct ExtendPolicy {
   double min_t, max_t;
   const int32_t *self_code;  // VertexBuf::self_code / self_dmin: a bounce ray sits at its vertex's entry
   const float *dmin;
+  v3 cam_o;  // where every camera ray starts (a list-less launch traces camera rays: k_generate does not store their origins)
   __device__ __forceinline__ double min_t_all() const { return min_t; }
   // false: the slot holds no ray (see k_generate); its hit record says so
   __device__ __forceinline__ bool load(uint32_t i, v3 &o, v3 &d, double &tmax, uint32_t &self) const {
@@ -29,7 +30,7 @@ struct ExtendPolicy {
       hb.prim[i] = PRIM_UNUSED;
       return false;
     }
-    o = V(q.o[0][j], q.o[1][j], q.o[2][j]);
+    o = list ? V(q.o[0][j], q.o[1][j], q.o[2][j]) : cam_o;
     tmax = max_t;
     return true;
   }
@@ -42,11 +43,11 @@ struct ExtendPolicy {
 template <bool COUNT>
 __global__ void TRAV_BOUNDS_N(PTAMD_WAVES_EXTEND)
     k_extend(DevScene S, RayQ q, const int32_t *__restrict__ list, HitBuf hb, Ctl *ctl, double min_t, double max_t,
-             uint2 *gstack, const int32_t *__restrict__ self_code, const float *__restrict__ self_dmin) {
+             uint2 *gstack, const int32_t *__restrict__ self_code, const float *__restrict__ self_dmin, v3 cam_o) {
   extern __shared__ uint2 lds_stack[];
   const TravStack stack{(lds_uint2 *)lds_stack, gstack, gridDim.x * blockDim.x, blockIdx.x * blockDim.x + threadIdx.x, PTAMD_STACK_EXTEND};
   uint32_t cn = 0, ct = 0, cx = 0;
-  const ExtendPolicy pol{q, list, hb, min_t, max_t, self_code, self_dmin};
+  const ExtendPolicy pol{q, list, hb, min_t, max_t, self_code, self_dmin, cam_o};
   PTAMD_WAVELOG_BEGIN
   trace_rays<0, COUNT, PTAMD_REFILL_EXTEND>(S, pol, ctl->n_cur, &ctl->grab[0], stack, cn, ct, cx);
   PTAMD_WAVELOG_END(S)
@@ -144,7 +145,7 @@ __global__ void TRAV_BOUNDS_N(PTAMD_WAVES_EXTEND)
   extern __shared__ uint2 lds_stack[];
   const TravStack stack{(lds_uint2 *)lds_stack, gstack, gridDim.x * blockDim.x, blockIdx.x * blockDim.x + threadIdx.x, PTAMD_STACK_EXTEND};
   uint32_t cn = 0, ct = 0, cx = 0;
-  const ExtendPolicy pe{q, list, hb, PT_EPS_D, (double)INFINITY, vb.self_code, vb.self_dmin};
+  const ExtendPolicy pe{q, list, hb, PT_EPS_D, (double)INFINITY, vb.self_code, vb.self_dmin, V(0, 0, 0)};  // (always a list)
   for (int k = 0; k < 3; k++) vb.hp[k] = q.o[k];  // the same arrays (see ptamd_trace_list): one set of pointers to hold
   const ShadowPolicy<HEMI> ps{S, sq, vb, by_nls, nls_nsa.x, nls_nsa.y};
   // Short lists are traced together (one drain phase instead of two, see trace_two_lists). Long
@@ -166,8 +167,8 @@ __global__ void TRAV_BOUNDS_N(PTAMD_WAVES_EXTEND)
   }
 }
 
-template __global__ void k_extend<false>(DevScene, RayQ, const int32_t *, HitBuf, Ctl *, double, double, uint2 *, const int32_t *, const float *);
-template __global__ void k_extend<true>(DevScene, RayQ, const int32_t *, HitBuf, Ctl *, double, double, uint2 *, const int32_t *, const float *);
+template __global__ void k_extend<false>(DevScene, RayQ, const int32_t *, HitBuf, Ctl *, double, double, uint2 *, const int32_t *, const float *, v3);
+template __global__ void k_extend<true>(DevScene, RayQ, const int32_t *, HitBuf, Ctl *, double, double, uint2 *, const int32_t *, const float *, v3);
 #define PTK_INST2(K, H, C) template __global__ void K<H, C>
 PTK_INST2(k_shadow, false, false)(DevScene, ShadowQ, VertexBuf, Ctl *, FastDiv, uint2, uint2 *, uint32_t);
 PTK_INST2(k_shadow, false, true)(DevScene, ShadowQ, VertexBuf, Ctl *, FastDiv, uint2, uint2 *, uint32_t);

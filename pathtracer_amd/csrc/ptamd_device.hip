@@ -16,7 +16,10 @@
 //
 // The shadow rays of depth d and the bounce rays of depth d + 1 are both ready once
 // depth d is shaded and are traced by ONE launch (k_trace2); k_extend only traces
-// the camera rays and k_shadow the last depth's shadow rays.
+// the camera rays and k_shadow the last depth's shadow rays and lists too long to share
+// a launch. Where the shading of a depth leaves the paths' sums alone, `resolve` of depth
+// d runs as workgroups of the launch that draws depth d + 1's light samples
+// (k_light_resolve): one is bound by memory round trips, the other by instruction issue.
 //
 // and finally `accumulate` folds the finished paths into the per-pixel sums in
 // sample order, applying the adaptive test between batches, exactly as
@@ -715,7 +718,7 @@ int ptamd_trace_list(ptamd_context *c, const ptamd_pixel_list *list, int32_t sam
       if (fp.max_ray_depth > 0 && fp.nls > 0) {
         uint32_t shadow_skip = 0;  // k_shadow skips lists that k_trace2 has traced: those shorter than this
         if (depth < depths && c->trace_two) {
-          // the next depth's bounce rays (queue cur ^ 1, just written) together with this depth's shadow rays;
+          // the next depth's bounce rays (queue qo, just written) together with this depth's shadow rays;
           // the hit records of this depth have been consumed by k_shade
           L.begin(PTAMD_K_TRACE2);
           PTAMD_WAVELOG_NEXT(c, 1, egrid);

@@ -663,6 +663,33 @@ __global__ void __launch_bounds__(256)
     }
     // shadow rays, in slot order (vertex-major: the samples of one vertex stay adjacent)
     uint32_t run = cp.cnt_shadow[vbk];
+    if ((nls & 3) == 0) {
+      // one thread per entry, its nls visibility bytes read as words: an exclusive scan of the entries' counts
+      // over the workgroup, then every thread writes its own slots (one pass and two barriers instead of nls)
+      const uint8_t *vrow = vb.vis + (size_t)i * nls;
+      uint32_t mine = 0;
+      if (i < n)
+        for (int w = 0; w < nls; w += 4) mine += (uint32_t)__popc(*reinterpret_cast<const uint32_t *>(vrow + w) & 0x02020202u);
+      uint32_t incl = mine;
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t up = __shfl_up(incl, off);
+        if (lane >= off) incl += up;
+      }
+      if (lane == 63) wcnt[wv] = incl;
+      __syncthreads();
+      uint32_t at = run + incl - mine;
+      for (int k = 0; k < wv; k++) at += wcnt[k];
+      if (mine) {
+        for (int w = 0; w < nls; w += 4) {
+          const uint32_t vw = *reinterpret_cast<const uint32_t *>(vrow + w);
+#pragma unroll
+          for (int b = 0; b < 4; b++)
+            if ((vw >> (8 * b)) & 2u) sq.slot[at++] = (int32_t)((size_t)i * nls + w + b);
+        }
+      }
+      __syncthreads();
+      continue;
+    }
     const size_t slot0 = (size_t)(vbk << 8) * nls, slot_end = (size_t)n * nls;
     for (int c = 0; c < nls; c++) {
       const size_t s = slot0 + (size_t)c * 256 + threadIdx.x;

@@ -61,9 +61,12 @@ struct FrameParams {
   m3 c2w;
 };
 
+// One per path depth in flight: the kernels of depth d work on block d & 3 of a ring (CTL_RING), whose list lengths
+// the previous depth's k_scan2 has set; the statistics are summed over the ring when they are read.
+constexpr int CTL_RING = 4;
 struct Ctl {
   uint32_t n_cur, n_next, n_shadow, n_pix;  // sizes of the ray lists; pixels of the running chunk
-  uint32_t n_prev, pad_;  // the previous depth's n_cur (k_advance): k_light_resolve settles that depth's light samples
+  uint32_t n_prev, pad_;  // the previous depth's n_cur (set by that depth's k_scan2): k_light_resolve settles that depth's light samples
   uint32_t grab[4];  // next unclaimed ray of a list: [0] k_extend, [1] shadow rays, [2] bounce rays in k_trace2 (persistent drivers)
   unsigned long long st_rays, st_shadow, st_vertices, st_nodes, st_tests, st_samples, st_dead;
   unsigned long long st_exact;  // primitive tests that needed the FP64 path (counted with st_tests)

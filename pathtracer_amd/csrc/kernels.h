@@ -20,7 +20,6 @@ __global__ void k_trace2(DevScene S, RayQ q, const int32_t *__restrict__ list, H
 
 // ---- shade_kernels.hip
 __global__ void k_set_counts(Ctl *ctl, PixView pv, uint32_t p0, uint32_t chunk, uint32_t ns);
-__global__ void k_advance(Ctl *ctl);
 __global__ void k_plan_count(PixView pv, uint32_t p0, uint32_t chunk, RoundPlan rp, uint32_t *__restrict__ block_count);
 __global__ void k_plan_scan(uint32_t *block_count, uint32_t n_blocks, Ctl *ctl, PixView pv, uint32_t p0, uint32_t chunk);
 __global__ void k_plan_offsets(PixView pv, uint32_t p0, Ctl *ctl, RoundPlan rp, const uint32_t *__restrict__ block_offset,
@@ -32,7 +31,7 @@ template <bool HEMI>
 __global__ void k_shade(FrameParams fp, DevScene S, RayQ q, const int32_t *__restrict__ list, HitBuf hb, RayQ qn, ShadowQ sq,
                         VertexBuf vb, PathBuf pb, Compact cp, Ctl *ctl, int32_t depth);
 __global__ void k_light(FrameParams fp, DevScene S, VertexBuf vb, ShadowQ sq, Compact cp, Ctl *ctl, FastDiv by_nls, uint32_t rng_base);
-__global__ void k_scan2(Compact cp, Ctl *ctl);
+__global__ void k_scan2(Compact cp, Ctl *ctl, Ctl *next);
 __global__ void k_scatter(Compact cp, VertexBuf vb, int32_t *__restrict__ list_next, ShadowQ sq, Ctl *ctl, int32_t nls);
 __global__ void k_resolve(FrameParams fp, DevScene S, RayQ q, const int32_t *__restrict__ list, VertexBuf vb,
                           const SRay *__restrict__ rays, PathBuf pb, Ctl *ctl, int32_t depth);

@@ -392,7 +392,7 @@ int ptamd_create(int32_t device_id, ptamd_context **out) {
   if (const char *e = getenv("PTAMD_PLAN_MARGIN")) { const double m = atof(e); if (m >= 1.0 && m <= 8.0) c->plan_margin = m; }
   // The counters live apart from the work buffers: those are reallocated when a later round needs
   // more room, and a frame's statistics must survive that.
-  if (hipMalloc((void **)&c->ctl, sizeof(Ctl)) != hipSuccess || hipMemset(c->ctl, 0, sizeof(Ctl)) != hipSuccess) {
+  if (hipMalloc((void **)&c->ctl, CTL_RING * sizeof(Ctl)) != hipSuccess || hipMemset(c->ctl, 0, CTL_RING * sizeof(Ctl)) != hipSuccess) {
     ptamd::set_error("cannot allocate the device-side counters");
     ptamd_destroy(c);
     return PTAMD_ERR_DEVICE;
@@ -636,7 +636,7 @@ int ptamd_trace_list(ptamd_context *c, const ptamd_pixel_list *list, int32_t sam
   rc = traversal_launch(c, &tl);
   if (rc) return rc;
   if (c->clear_ctl) {
-    HIPCHK(hipMemsetAsync(c->ctl, 0, sizeof(Ctl), s));
+    HIPCHK(hipMemsetAsync(c->ctl, 0, CTL_RING * sizeof(Ctl), s));
     c->clear_ctl = false;
   }
   const int tblock = tl.block;
@@ -660,16 +660,17 @@ int ptamd_trace_list(ptamd_context *c, const ptamd_pixel_list *list, int32_t sam
   const int depths = std::max(1, fp.max_ray_depth);
   for (int64_t p0 = 0; p0 < n; p0 += px_per_chunk) {
     const uint32_t up0 = (uint32_t)p0;
+    Ctl *const ctl1 = c->ctl + 1;  // the control block of depth 1 (depth d: block d & 3)
     L.begin(PTAMD_K_GENERATE);
     if (packed) {
       const uint32_t nb = (uint32_t)((std::min<int64_t>(px_per_chunk, n - p0) + 255) / 256);
       hipLaunchKernelGGL(k_plan_count, nb, 256, 0, s, pv, up0, (uint32_t)px_per_chunk, rp, c->plan_blocks);
-      hipLaunchKernelGGL(k_plan_scan, 1, 1024, 0, s, c->plan_blocks, nb, c->ctl, pv, up0, (uint32_t)px_per_chunk);
-      hipLaunchKernelGGL(k_plan_offsets, nb, 256, 0, s, pv, up0, c->ctl, rp, (const uint32_t *)c->plan_blocks, c->pix_off, c->slot_pix);
+      hipLaunchKernelGGL(k_plan_scan, 1, 1024, 0, s, c->plan_blocks, nb, ctl1, pv, up0, (uint32_t)px_per_chunk);
+      hipLaunchKernelGGL(k_plan_offsets, nb, 256, 0, s, pv, up0, ctl1, rp, (const uint32_t *)c->plan_blocks, c->pix_off, c->slot_pix);
     } else {
-      hipLaunchKernelGGL(k_set_counts, 1, 1, 0, s, c->ctl, pv, up0, (uint32_t)px_per_chunk, (uint32_t)n_samples);
+      hipLaunchKernelGGL(k_set_counts, 1, 1, 0, s, ctl1, pv, up0, (uint32_t)px_per_chunk, (uint32_t)n_samples);
     }
-    hipLaunchKernelGGL(k_generate, ggrid, 256, 0, s, fp, c->S, pv, up0, c->ctl, rp, pm, c->q[0], pb);
+    hipLaunchKernelGGL(k_generate, ggrid, 256, 0, s, fp, c->S, pv, up0, ctl1, rp, pm, c->q[0], pb);
     L.end();
     int cur = 0;   // list[cur]: this depth's list, list[cur ^ 1]: the next one's
     int qi = 0;    // q[qi]: this depth's rays, q[qo]: the next depth's (its origin arrays hold this depth's hit points)
@@ -678,14 +679,15 @@ int ptamd_trace_list(ptamd_context *c, const ptamd_pixel_list *list, int32_t sam
     bool traced_ahead = false;  // this depth's bounce rays went with the previous depth's shadow rays (k_trace2)
     for (int depth = 1; depth <= depths; depth++) {
       const int qo = (qi + 1) % nq, par = overlap ? (depth & 1) : 0;
+      Ctl *const ctl = c->ctl + (depth & (CTL_RING - 1)), *const ctl_next = c->ctl + ((depth + 1) & (CTL_RING - 1));
       const double min_t = depth == 1 ? fp.n_clip : PT_EPS_D;
       const double max_t = depth == 1 ? fp.f_clip : (double)INFINITY;
       const int32_t *lst = depth == 1 ? nullptr : c->list[cur];
       if (!traced_ahead) {
         L.begin(PTAMD_K_EXTEND);
         PTAMD_WAVELOG_NEXT(c, 0, egrid);
-        if (c->prof_counters) hipLaunchKernelGGL((k_extend<true>), egrid, tblock, elds, s, c->S, c->q[qi], lst, c->hb, c->ctl, min_t, max_t, gstack, (const int32_t *)c->vb.self_code, (const float *)c->vb.self_dmin, fp.cam_pos);
-        else hipLaunchKernelGGL((k_extend<false>), egrid, tblock, elds, s, c->S, c->q[qi], lst, c->hb, c->ctl, min_t, max_t, gstack, (const int32_t *)c->vb.self_code, (const float *)c->vb.self_dmin, fp.cam_pos);
+        if (c->prof_counters) hipLaunchKernelGGL((k_extend<true>), egrid, tblock, elds, s, c->S, c->q[qi], lst, c->hb, ctl, min_t, max_t, gstack, (const int32_t *)c->vb.self_code, (const float *)c->vb.self_dmin, fp.cam_pos);
+        else hipLaunchKernelGGL((k_extend<false>), egrid, tblock, elds, s, c->S, c->q[qi], lst, c->hb, ctl, min_t, max_t, gstack, (const int32_t *)c->vb.self_code, (const float *)c->vb.self_dmin, fp.cam_pos);
         L.end();
       }
       traced_ahead = false;
@@ -697,23 +699,23 @@ int ptamd_trace_list(ptamd_context *c, const ptamd_pixel_list *list, int32_t sam
       L.begin(PTAMD_K_SHADE);
       if (fp.hemisphere)
         hipLaunchKernelGGL(k_shade<true>, shade_grid, 256, 0, s, fp, c->S, c->q[qi], lst, c->hb, c->q[qo], sq, vb, pb,
-                           c->cp, c->ctl, depth);
+                           c->cp, ctl, depth);
       else
         hipLaunchKernelGGL(k_shade<false>, shade_grid, 256, 0, s, fp, c->S, c->q[qi], lst, c->hb, c->q[qo], sq, vb, pb,
-                           c->cp, c->ctl, depth);
+                           c->cp, ctl, depth);
       L.end();
       if (!fp.hemisphere && fp.max_ray_depth > 0 && fp.nls > 0) {
         L.begin(PTAMD_K_LIGHT);
         const uint32_t rng_base = 1u + (uint32_t)(depth - 1) * (uint32_t)fp.bpv;
         if (overlap && depth > 1)  // with the previous depth's k_resolve: at most light_grid + shade_grid workgroups have work
-          hipLaunchKernelGGL(k_light_resolve, light_grid + shade_grid, 256, 0, s, fp, c->S, vb, sq, c->cp, c->ctl, by_nls, rng_base, prev);
+          hipLaunchKernelGGL(k_light_resolve, light_grid + shade_grid, 256, 0, s, fp, c->S, vb, sq, c->cp, ctl, by_nls, rng_base, prev);
         else
-          hipLaunchKernelGGL(k_light, light_grid, 256, 0, s, fp, c->S, vb, sq, c->cp, c->ctl, by_nls, rng_base);
+          hipLaunchKernelGGL(k_light, light_grid, 256, 0, s, fp, c->S, vb, sq, c->cp, ctl, by_nls, rng_base);
         L.end();
       }
       L.begin(PTAMD_K_OTHER);
-      hipLaunchKernelGGL(k_scan2, 1, 1024, 0, s, c->cp, c->ctl);
-      hipLaunchKernelGGL(k_scatter, ggrid, 256, 0, s, c->cp, vb, c->list[cur ^ 1], sq, c->ctl, fp.max_ray_depth > 0 ? fp.nls : 0);
+      hipLaunchKernelGGL(k_scan2, 1, 1024, 0, s, c->cp, ctl, ctl_next);
+      hipLaunchKernelGGL(k_scatter, ggrid, 256, 0, s, c->cp, vb, c->list[cur ^ 1], sq, ctl, fp.max_ray_depth > 0 ? fp.nls : 0);
       L.end();
       if (fp.max_ray_depth > 0 && fp.nls > 0) {
         uint32_t shadow_skip = 0;  // k_shadow skips lists that k_trace2 has traced: those shorter than this
@@ -723,7 +725,7 @@ int ptamd_trace_list(ptamd_context *c, const ptamd_pixel_list *list, int32_t sam
           L.begin(PTAMD_K_TRACE2);
           PTAMD_WAVELOG_NEXT(c, 1, egrid);
           const bool hemi = fp.hemisphere != 0, cnt = c->prof_counters;
-#define PTAMD_LAUNCH_TRACE2(H, C) hipLaunchKernelGGL((k_trace2<H, C>), egrid, tblock, elds, s, c->S, c->q[qo], (const int32_t *)c->list[cur ^ 1], c->hb, sq, vb, c->ctl, by_nls, nls_nsa, gstack, c->fuse_below)
+#define PTAMD_LAUNCH_TRACE2(H, C) hipLaunchKernelGGL((k_trace2<H, C>), egrid, tblock, elds, s, c->S, c->q[qo], (const int32_t *)c->list[cur ^ 1], c->hb, sq, vb, ctl, by_nls, nls_nsa, gstack, c->fuse_below)
           if (hemi) { if (cnt) PTAMD_LAUNCH_TRACE2(true, true); else PTAMD_LAUNCH_TRACE2(true, false); }
           else { if (cnt) PTAMD_LAUNCH_TRACE2(false, true); else PTAMD_LAUNCH_TRACE2(false, false); }
 #undef PTAMD_LAUNCH_TRACE2
@@ -739,36 +741,28 @@ int ptamd_trace_list(ptamd_context *c, const ptamd_pixel_list *list, int32_t sam
           L.begin(PTAMD_K_SHADOW);
           PTAMD_WAVELOG_NEXT(c, 2, sgrid);
           if (fp.hemisphere) {
-            if (c->prof_counters) hipLaunchKernelGGL((k_shadow<true, true>), sgrid, tblock, slds, s, c->S, sq, vb, c->ctl, by_nls, nls_nsa, gstack, shadow_skip);
-            else hipLaunchKernelGGL((k_shadow<true, false>), sgrid, tblock, slds, s, c->S, sq, vb, c->ctl, by_nls, nls_nsa, gstack, shadow_skip);
+            if (c->prof_counters) hipLaunchKernelGGL((k_shadow<true, true>), sgrid, tblock, slds, s, c->S, sq, vb, ctl, by_nls, nls_nsa, gstack, shadow_skip);
+            else hipLaunchKernelGGL((k_shadow<true, false>), sgrid, tblock, slds, s, c->S, sq, vb, ctl, by_nls, nls_nsa, gstack, shadow_skip);
           } else {
-            if (c->prof_counters) hipLaunchKernelGGL((k_shadow<false, true>), sgrid, tblock, slds, s, c->S, sq, vb, c->ctl, by_nls, nls_nsa, gstack, shadow_skip);
-            else hipLaunchKernelGGL((k_shadow<false, false>), sgrid, tblock, slds, s, c->S, sq, vb, c->ctl, by_nls, nls_nsa, gstack, shadow_skip);
+            if (c->prof_counters) hipLaunchKernelGGL((k_shadow<false, true>), sgrid, tblock, slds, s, c->S, sq, vb, ctl, by_nls, nls_nsa, gstack, shadow_skip);
+            else hipLaunchKernelGGL((k_shadow<false, false>), sgrid, tblock, slds, s, c->S, sq, vb, ctl, by_nls, nls_nsa, gstack, shadow_skip);
           }
           L.end();
         }
         if (overlap && depth < depths) {
           // summed by the next depth's k_light_resolve
           prev = ResolveArgs{c->q[qi], lst, vb, (const SRay *)sq.ray, pb, depth};
-          L.begin(PTAMD_K_OTHER);
-          hipLaunchKernelGGL(k_advance, 1, 1, 0, s, c->ctl);
-          L.end();
         } else {
           L.begin(PTAMD_K_RESOLVE);
-          hipLaunchKernelGGL(k_resolve, shade_grid, 256, 0, s, fp, c->S, c->q[qi], lst, vb, (const SRay *)sq.ray, pb, c->ctl, depth);
-          hipLaunchKernelGGL(k_advance, 1, 1, 0, s, c->ctl);
+          hipLaunchKernelGGL(k_resolve, shade_grid, 256, 0, s, fp, c->S, c->q[qi], lst, vb, (const SRay *)sq.ray, pb, ctl, depth);
           L.end();
         }
-      } else {
-        L.begin(PTAMD_K_OTHER);
-        hipLaunchKernelGGL(k_advance, 1, 1, 0, s, c->ctl);
-        L.end();
       }
       cur ^= 1;
       qi = qo;
     }
     L.begin(PTAMD_K_ACCUMULATE);
-    hipLaunchKernelGGL(k_accumulate, ggrid, 256, 0, s, pv, up0, c->ctl, rp, pm, pb, d_state);
+    hipLaunchKernelGGL(k_accumulate, ggrid, 256, 0, s, pv, up0, ctl1, rp, pm, pb, d_state);
     L.end();
   }
   HIPCHK(hipGetLastError());
@@ -912,8 +906,13 @@ int ptamd_get_stats(ptamd_context *c, ptamd_stats *out) {
   HIPCHK(hipDeviceSynchronize());
   collect_events(c);
   if (c->ctl) {
-    Ctl h;
-    HIPCHK(hipMemcpy(&h, c->ctl, sizeof h, hipMemcpyDeviceToHost));
+    Ctl ring[CTL_RING], h{};  // the statistics of a frame are spread over the depths' control blocks
+    HIPCHK(hipMemcpy(ring, c->ctl, sizeof ring, hipMemcpyDeviceToHost));
+    for (const Ctl &r : ring) {
+      h.st_rays += r.st_rays; h.st_shadow += r.st_shadow; h.st_vertices += r.st_vertices; h.st_nodes += r.st_nodes;
+      h.st_tests += r.st_tests; h.st_exact += r.st_exact; h.st_samples += r.st_samples; h.st_dead += r.st_dead;
+      h.st_two_ext += r.st_two_ext; h.st_two_shadow += r.st_two_shadow;
+    }
     c->stats.rays = h.st_rays - h.st_dead;  // path slots a round left unused are not rays
     c->stats.shadow_rays = h.st_shadow;
     c->stats.path_vertices = h.st_vertices;

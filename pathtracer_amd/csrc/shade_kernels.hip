@@ -98,18 +98,6 @@ __global__ void k_plan_offsets(PixView pv, uint32_t p0, Ctl *ctl, RoundPlan rp, 
   if (p + 1 == np) off[np] = pre + x;  // == ctl->n_cur
 }
 
-// end of one depth: fold the stage's counts into the statistics, make the next
-// queue current
-__global__ void k_advance(Ctl *ctl) {
-  ctl->st_rays += (unsigned long long)ctl->n_cur + ctl->n_shadow;
-  ctl->st_shadow += ctl->n_shadow;
-  ctl->n_prev = ctl->n_cur;
-  ctl->n_cur = ctl->n_next;
-  ctl->n_next = 0;
-  ctl->n_shadow = 0;
-  ctl->grab[0] = ctl->grab[1] = ctl->grab[2] = 0;
-}
-
 // Camera::generate_ray, src/pathtracer/camera.cpp:190-203
 __device__ __forceinline__ void camera_ray(const FrameParams &fp, double x, double y, v3 &o, v3 &d) {
   const v3 sensor = V((x - 0.5) * 2 * fp.tan_h, (y - 0.5) * 2 * fp.tan_v, -1);
@@ -569,8 +557,11 @@ __global__ void __launch_bounds__(256)
 }
 
 // Exclusive scan of the two per-block count arrays (one workgroup); the totals
-// become the sizes of the next ray list and of the shadow-ray list.
-__global__ void __launch_bounds__(1024) k_scan2(Compact cp, Ctl *ctl) {
+// become the sizes of the next ray list and of the shadow-ray list. This is also where a depth ends for the
+// counters: every depth has a control block of its own (a ring of four, ptamd_trace_list), and the one
+// workgroup that knows this depth's totals sets up the next depth's block (its list length, the length of the
+// list before it, fresh claim counters) and folds the totals into the statistics, which saves a launch per depth.
+__global__ void __launch_bounds__(1024) k_scan2(Compact cp, Ctl *ctl, Ctl *next) {
   // per pass: IT counts per thread summed serially (read and written sixteen bytes at a time), a shuffle scan
   // inside each wave, the 16 wave totals through LDS (three barriers per 1024 x IT counts: the kernel is one
   // workgroup and its time is the number of passes, two for the 65536 blocks of a 16 Mi-path launch)
@@ -635,8 +626,17 @@ __global__ void __launch_bounds__(1024) k_scan2(Compact cp, Ctl *ctl) {
     __syncthreads();
   }
   if (threadIdx.x == 0) {
+    const uint32_t n_cur = ctl->n_cur;
     ctl->n_next = carry[0];
     ctl->n_shadow = carry[1];
+    ctl->st_rays += (unsigned long long)n_cur + carry[1];
+    ctl->st_shadow += carry[1];
+    next->n_pix = ctl->n_pix;
+    next->n_prev = n_cur;
+    next->n_cur = carry[0];
+    next->n_next = 0;
+    next->n_shadow = 0;
+    next->grab[0] = next->grab[1] = next->grab[2] = 0;
   }
 }
 

@@ -61,6 +61,10 @@ CASES = [
     ("CBspheres_lambertian", 64, 48, dict(ns_aa=32, max_ray_depth=2, ns_area_light=2, hemisphere=True, accumulate_bounces=False)),
     ("CBempty", 64, 48, dict(ns_aa=32, max_ray_depth=4, ns_area_light=4)),
     ("CBcoil", 64, 48, dict(ns_aa=16, max_ray_depth=5, ns_area_light=2)),
+    # light samples per vertex beyond one word of visibility bytes (k_scatter, k_resolve read them four at a time),
+    # and an odd count above four (their byte-wise paths)
+    ("CBspheres_lambertian", 64, 48, dict(ns_aa=16, max_ray_depth=4, ns_area_light=8)),
+    ("CBspheres_lambertian", 48, 36, dict(ns_aa=16, max_ray_depth=3, ns_area_light=5)),
     # -a 1 tol: the adaptive test runs before every sample from the second on; at i = 1 it is
     # 0 * inf = NaN, which lets the pixel go on (pathtracer.cpp:250-258)
     ("CBspheres_lambertian", 48, 36, dict(ns_aa=12, max_ray_depth=2, ns_area_light=1, samples_per_batch=1, max_tolerance=0.3)),

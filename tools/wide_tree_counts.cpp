@@ -13,7 +13,9 @@
 // them in node order and stop at the first hit: the device walk's two policies. Boxes and primitive tests
 // are FP64 here (the counts do not depend on the device's conservative FP32 forms to first order).
 // Printed per width and ray kind: node visits, child boxes tested, primitive tests, and "trips" of the
-// device schedule for one lane (two node steps then one primitive step per trip).
+// device schedule for one lane (two node steps then one primitive step per trip). Two more pairs of rows: 4- and
+// 8-wide with the binary tree's leaves kept whole (one child, its primitives tested in one step), and 4- and 8-wide
+// collapsed by a dynamic programme for the least summed node area instead of the device layer's greedy rule.
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -94,6 +96,89 @@ static WTree collapse(const ptamd_scene_desc &d, int W, bool leaves = false) {
   }
   return T;
 }
+
+// The collapse that minimises the summed surface area of the wide nodes (= the expected number of node visits of a
+// random ray under the surface-area heuristic): a dynamic programme over the binary tree. f(n, i) = least summed area of
+// the wide nodes made inside subtree n when n may take up to i child slots of the wide node above it: either n becomes a
+// wide node itself (one slot; its own W slots are split between its two children) or, with i >= 2, it dissolves and
+// its children share the i slots. A leaf of m primitives is a little subtree of single primitives (each its own child).
+struct OptCollapse {
+  const ptamd_scene_desc &d; int W;
+  // virtual binary tree: ids < N are the scene's nodes; leaves with m > 1 primitives get m - 1 virtual inner nodes
+  struct VN { int l, r, prim; double area; };  // prim >= 0: a single primitive
+  std::vector<VN> v; std::vector<std::vector<double>> f; std::vector<std::vector<signed char>> choice;  // choice[n][i]: 0 = node, k > 0 = dissolve, left gets k
+  std::vector<std::vector<signed char>> split_node;  // as a wide node: left gets k of W
+  static double area6(const double *bb) { const double ex = bb[3] - bb[0], ey = bb[4] - bb[1], ez = bb[5] - bb[2]; return ex * ey + ey * ez + ez * ex; }
+  int build(int n) {  // returns the virtual id of scene node n
+    if (d.node_count[n] > 0) {
+      int cur = -1;
+      for (int p = d.node_start[n]; p < d.node_start[n] + d.node_count[n]; p++) {
+        v.push_back({-1, -1, p, 0.0}); const int leaf = (int)v.size() - 1;
+        if (cur < 0) cur = leaf;
+        else {
+          // a left-deep chain over the leaf's primitives; boxes of the partial unions
+          double bb[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
+          for (int q = d.node_start[n]; q <= p; q++) { double pb[6]; prim_box(d, q, pb); for (int k = 0; k < 3; k++) { bb[k] = std::min(bb[k], pb[k]); bb[3 + k] = std::max(bb[3 + k], pb[3 + k]); } }
+          v.push_back({cur, leaf, -1, area6(bb)}); cur = (int)v.size() - 1;
+        }
+      }
+      return cur;
+    }
+    const int l = build(d.node_left[n]), r = build(d.node_right[n]);
+    v.push_back({l, r, -1, area6(d.node_bbox + 6 * (size_t)n)});
+    return (int)v.size() - 1;
+  }
+  void solve(int n) {
+    f[n].assign(W + 1, 0.0); choice[n].assign(W + 1, 0); split_node[n].assign(1, 0);
+    if (v[n].prim >= 0) return;
+    solve(v[n].l); solve(v[n].r);
+    auto g = [&](int j, int &bestk) { double best = INFINITY; bestk = 1; for (int k = 1; k < j; k++) { const double c = f[v[n].l][k] + f[v[n].r][j - k]; if (c < best) { best = c; bestk = k; } } return best; };
+    int kn; const double as_node = v[n].area + g(W, kn); split_node[n][0] = (signed char)kn;
+    f[n][1] = as_node; choice[n][1] = 0;
+    for (int i = 2; i <= W; i++) {
+      int kd; const double dis = g(i, kd);
+      f[n][i] = as_node; choice[n][i] = 0;
+      if (dis < f[n][i]) { f[n][i] = dis; choice[n][i] = (signed char)kd; }
+      if (f[n][i - 1] < f[n][i]) { f[n][i] = f[n][i - 1]; choice[n][i] = choice[n][i - 1]; if (choice[n][i - 1] == 0) choice[n][i] = 0; else choice[n][i] = -(signed char)(i - 1); }
+    }
+  }
+  // the child slots subtree n presents when given i slots
+  void emit(int n, int i, std::vector<int> &slots) {
+    if (v[n].prim >= 0) { slots.push_back(~v[n].prim); return; }
+    int c = choice[n][i];
+    while (c < 0) { i = -c; c = choice[n][i]; }  // "use only i - 1 slots"
+    if (c == 0) { slots.push_back(n); return; }  // a wide node of its own
+    emit(v[n].l, c, slots); emit(v[n].r, i - c, slots);
+  }
+  WTree run() {
+    v.reserve(4 * (size_t)d.n_nodes);
+    const int root = build(d.root);
+    f.resize(v.size()); choice.resize(v.size()); split_node.resize(v.size());
+    solve(root);
+    WTree T; T.nodes.push_back({});
+    std::vector<std::pair<int, int>> work{{0, root}};
+    while (!work.empty()) {
+      auto [id, n] = work.back(); work.pop_back();
+      std::vector<int> slots;
+      if (v[n].prim >= 0) slots.push_back(~v[n].prim);
+      else { const int k = split_node[n][0]; emit(v[n].l, k, slots); emit(v[n].r, W - k, slots); }
+      for (int sc : slots) {
+        std::array<double, 6> bb;
+        if (sc < 0) prim_box(d, ~sc, bb.data());
+        else {
+          // box of virtual node sc: union of the primitives below it
+          for (int k = 0; k < 3; k++) { bb[k] = INFINITY; bb[3 + k] = -INFINITY; }
+          std::vector<int> st{sc};
+          while (!st.empty()) { const int x = st.back(); st.pop_back(); if (v[x].prim >= 0) { double pb[6]; prim_box(d, v[x].prim, pb); for (int k = 0; k < 3; k++) { bb[k] = std::min(bb[k], pb[k]); bb[3 + k] = std::max(bb[3 + k], pb[3 + k]); } } else { st.push_back(v[x].l); st.push_back(v[x].r); } }
+        }
+        T.nodes[id].box.push_back(bb);
+        if (sc < 0) T.nodes[id].child.push_back(sc);
+        else { T.nodes[id].child.push_back((int)T.nodes.size()); work.push_back({(int)T.nodes.size(), sc}); T.nodes.push_back({}); }
+      }
+    }
+    return T;
+  }
+};
 
 static bool box_hit(const std::array<double, 6> &b, V3 o, V3 inv, double tmin, double tmax, double &tn) {
   double t0 = tmin, t1 = tmax;
@@ -191,10 +276,10 @@ int main(int argc, char **argv) {
   int la = -1;
   for (int li = 0; li < d.n_lights; li++) if (d.light_kind[li] == PTAMD_LIGHT_AREA) { la = li; break; }
   printf("%s: %d primitives, %d binary nodes\n", argv[1], d.n_prims, d.n_nodes);
-  for (int mode = 0; mode < 6; mode++) {
-    const int W = mode < 4 ? (2 << mode) : (mode == 4 ? 4 : 8);
-    const bool leaves = mode >= 4;
-    const WTree T = collapse(d, W, leaves);
+  for (int mode = 0; mode < 8; mode++) {
+    const int W = mode < 4 ? (2 << mode) : (mode == 4 || mode == 6 ? 4 : 8);
+    const bool leaves = mode == 4 || mode == 5, optimal = mode >= 6;
+    const WTree T = optimal ? OptCollapse{d, W}.run() : collapse(d, W, leaves);
     size_t children = 0, prim_children = 0;
     for (auto &n : T.nodes) { children += n.child.size(); for (int c : n.child) prim_children += c < 0; }
     Counts cam_c, bounce_c, shadow_c;
@@ -251,7 +336,7 @@ int main(int argc, char **argv) {
       if (leaves) printf("  leaf steps %5.2f", C.leaf_steps / C.rays);
       printf("\n");
     };
-    printf(" W=%d%s: %zu nodes, %.2f children per node (%.2f of them %s)\n", W, leaves ? " with whole leaves" : "", T.nodes.size(),
+    printf(" W=%d%s%s: %zu nodes, %.2f children per node (%.2f of them %s)\n", W, leaves ? " with whole leaves" : "", optimal ? " collapsed for the least summed node area" : "", T.nodes.size(),
            (double)children / T.nodes.size(), (double)prim_children / T.nodes.size(), leaves ? "leaves" : "primitives");
     pr("camera", cam_c); pr("bounce", bounce_c); pr("shadow", shadow_c);
   }

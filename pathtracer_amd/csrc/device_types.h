@@ -198,7 +198,7 @@ struct RoundPlan {
       const double s1 = st[0], s2 = st[1];
       const double mean = s1 / n, var = (s2 - s1 * s1 / n) / (n - 1);
       const double c = 1.96 / tol;
-      // margin (1.5): erring on the long side costs a few dropped samples, erring on the short side a round
+      // margin: erring on the long side costs a few dropped samples, erring on the short side a round
       const double need = margin * (c * c * var / (mean * mean) - n);
       if (need == need) {  // not NaN
         double kb = ceil(need / batch);

@@ -135,7 +135,7 @@ def _all_gather_rows(dist, recv, send, group, on_gpu):
 
 def render_frame(dev, params, rank=0, world=1, group=None, device=None, record_rounds=None, lag=1,
                  pixel_stride=1, target_paths=16 << 20, max_batches=32, per_pixel=None, sync_below=None,
-                 exchange="frame", pixel_offset=0):
+                 exchange="frame", pixel_offset=0, growth=None):
     """Renders one frame; returns (hdr[h,w,3], count[h,w]) as tensors on `device`, on every rank.
 
     dev: api.Device with scene and camera set. With world > 1 the default process
@@ -151,8 +151,15 @@ def render_frame(dev, params, rank=0, world=1, group=None, device=None, record_r
     always agree in size. record_rounds, if a list, receives (samples_done,
     bound, this rank's share of the bound) per round.
 
-    sync_below: bounds at or below this many pixels are not lagged (see the loop). Default: 16384
+    sync_below: bounds at or below this many pixels are not lagged (see the loop). Default: 200000
     with per_pixel (whose loop ends only when the list is seen to be empty), 0 otherwise.
+
+    growth (per_pixel only; default 4, 0: no limit): a round traces no pixel further ahead than this many
+    times the samples the rounds before it traced ahead. A prediction made from one or two batches
+    is rough, and a round sized for the whole remaining budget on such statistics traces (and
+    drops) up to a tenth more samples than it needs; with the limit the look-ahead grows
+    geometrically and the unlagged count, which alone would make a small rank's frame slower,
+    makes every frame faster.
 
     target_paths, max_batches: see PixelSchedule.batches (max_batches = 1 keeps to
     one batch per round, the reference's own cadence).
@@ -207,9 +214,12 @@ def render_frame(dev, params, rank=0, world=1, group=None, device=None, record_r
         rows_recv = torch.empty((world * m0, 6), dtype=torch.float64, device=device)
     dev.frame_begin(params)
     cur, done, bound = 0, 0, n0
+    ahead = 0
     batch = params.samples_per_batch
     if sync_below is None:
-        sync_below = 16384 if per_pixel else 0
+        sync_below = 200000 if per_pixel else 0
+    if growth is None:
+        growth = 4
     # per_pixel: `done` is the least count any listed pixel can have (a pixel gains at
     # least one batch per round), which bounds the number of rounds
     while done < params.ns_aa and bound > 0:
@@ -222,8 +232,9 @@ def render_frame(dev, params, rank=0, world=1, group=None, device=None, record_r
                             n_dev[nxt:].data_ptr(), stream)
             cur = nxt
             pending.append(reader.post(n_dev[cur:cur + 1]))
-            # (a short list is read back at once: waiting for its count idles the GPU for tens of
-            # microseconds, queueing a round for pixels that have all stopped costs a round of launches)
+            # (a list that is not long is read back at once: waiting for its count idles the GPU for tens of
+            # microseconds; a round sized by a count that is one round old looks less far ahead than it could,
+            # which costs rounds, and one queued for pixels that have all stopped costs a round of launches)
             while len(pending) > (lag if bound > sync_below else 0):
                 bound = min(bound, reader.read(pending.pop(0)))
             if bound == 0:
@@ -232,6 +243,9 @@ def render_frame(dev, params, rank=0, world=1, group=None, device=None, record_r
                                            first=(done == 0))
         if not per_pixel:
             ns = min(ns, params.ns_aa - done)
+        elif growth and ahead > 0:
+            ns = max(batch, min(ns, growth * ahead // batch * batch))
+        ahead += ns
         whole = cabi.PixelList(bufs[cur].data_ptr(), n_dev[cur:].data_ptr(), 0, bound, 0, 1)
         mine = cabi.PixelList(bufs[cur].data_ptr(), n_dev[cur:].data_ptr(), 0, bound, rank, world)
         if record_rounds is not None:

@@ -24,9 +24,10 @@ def main():
         d = json.load(open(found[-1]))
         b = d.get("bench", {})
         frames = b.get("steps", 3) + b.get("warmup", 1)  # the profiled run's frames (its short counters frame adds little)
-        print("== %s (%s): %.1f ms/frame %.4g samples/s; dominant %s frac %.3f" % (
-            wl, os.path.basename(found[-1]), b.get("ms_per_step", 0), b.get("value", 0), b.get("roofline", {}).get("kernel"),
-            b.get("roofline", {}).get("frac") or 0))
+        # (the run's own roofline line is not quoted: it priced its launches with the counters of the summaries
+        # present when it ran, i.e. of the set before; the rows below are this set's)
+        print("== %s (%s): %.1f ms/frame %.4g samples/s; dominant class %s" % (
+            wl, os.path.basename(found[-1]), b.get("ms_per_step", 0), b.get("value", 0), b.get("roofline", {}).get("kernel")))
         for k, mixk in ROWS:
             if k not in d["kernels"] or k not in d["pmc_sq"]:
                 continue

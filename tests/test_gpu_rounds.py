@@ -233,26 +233,27 @@ def test_one_call_frame_is_the_same_under_either_look_ahead_policy(device, monke
     """ptamd_render's own round loop: every pixel traced ahead from its own count as far as its statistics
     predict (the choice for frames of 16 batches per pixel or more) against all pixels in lockstep
     (PTAMD_PER_PIXEL, read by every call): same frame and counts bit for bit, and the per-pixel policy
-    traces fewer samples that are then dropped."""
+    traces fewer samples that are then dropped. Also with a sample budget that is no multiple of the batch."""
     w, h = 256, 192  # enough pixels for rounds that do not trace every sample at once
     sc = pt.Scene(scene_path("CBbunny"))
     device.upload(sc)
     device.set_camera(sc.camera(w, h))
-    p = cabi.make_params(w, h, ns_aa=512, max_ray_depth=3, ns_area_light=2, seed=5, samples_per_batch=16)
-    monkeypatch.delenv("PTAMD_PER_PIXEL", raising=False)
-    hdr_d, cnt_d = device.render(p)
-    rays_d = device.stats().rays
-    monkeypatch.setenv("PTAMD_PER_PIXEL", "0")
-    hdr_l, cnt_l = device.render(p)
-    rays_l = device.stats().rays
-    monkeypatch.setenv("PTAMD_PER_PIXEL", "1")
-    hdr_p, cnt_p = device.render(p)
-    rays_p = device.stats().rays
-    assert np.array_equal(cnt_d, cnt_l) and np.array_equal(hdr_d, hdr_l)
-    assert np.array_equal(cnt_d, cnt_p) and np.array_equal(hdr_d, hdr_p)
-    assert rays_d == rays_p, "512 samples in batches of 16: per-pixel is the default"
-    assert rays_p < rays_l
-    assert cnt_d.min() < 512 and cnt_d.max() == 512, "the frame must have pixels that stop early and pixels that do not"
+    for ns_aa, batch in ((512, 16), (530, 32)):
+        p = cabi.make_params(w, h, ns_aa=ns_aa, max_ray_depth=3, ns_area_light=2, seed=5, samples_per_batch=batch)
+        monkeypatch.delenv("PTAMD_PER_PIXEL", raising=False)
+        hdr_d, cnt_d = device.render(p)
+        rays_d = device.stats().rays
+        monkeypatch.setenv("PTAMD_PER_PIXEL", "0")
+        hdr_l, cnt_l = device.render(p)
+        rays_l = device.stats().rays
+        monkeypatch.setenv("PTAMD_PER_PIXEL", "1")
+        hdr_p, cnt_p = device.render(p)
+        rays_p = device.stats().rays
+        assert np.array_equal(cnt_d, cnt_l) and np.array_equal(hdr_d, hdr_l)
+        assert np.array_equal(cnt_d, cnt_p) and np.array_equal(hdr_d, hdr_p)
+        assert rays_d == rays_p, "16 batches per pixel or more: per-pixel is the default"
+        assert rays_p < rays_l
+        assert cnt_d.min() < ns_aa and cnt_d.max() == ns_aa, "the frame must have pixels that stop early and pixels that do not"
 
 
 @pytest.mark.skipif(_POLICY_OVERRIDDEN, reason="launch policy overridden in the environment")

@@ -1,6 +1,8 @@
 """ctypes binding of the ptamd C ABI (include/ptamd.h)."""
 import ctypes as C
+import importlib.util
 import os
+import sys
 
 import numpy as np
 
@@ -31,6 +33,33 @@ def lib_path():
     return os.environ.get("PTAMD_LIB") or os.path.join(_HERE, "libptamd.so")
 
 
+def _share_torch_hip_runtime():
+    """One HIP runtime per process, whatever the import order.
+
+    torch's ROCm wheels carry their own libamdhip64.so.7 and libhsa-runtime64.so.1, found through the RPATH of
+    torch's libraries; libptamd.so names the same sonames and finds ROCm's. The dynamic loader keeps whichever
+    copy came first for both users, and torch does not find the GPU through ROCm's copy once libptamd.so has
+    initialised it ("No HIP GPUs are available"), while libptamd.so works with either. So where torch is
+    installed its copy is loaded first, without importing torch (PTAMD_OWN_HIP_RUNTIME=1 leaves that out, for
+    processes that never use torch and want the HIP runtime libptamd.so was linked against)."""
+    if "torch" in sys.modules or os.environ.get("PTAMD_OWN_HIP_RUNTIME"):
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.submodule_search_locations:
+        return
+    libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        path = os.path.join(libdir, name)
+        if os.path.exists(path):
+            try:
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+            except OSError:
+                return
+
+
 def lib():
     """Loads libptamd.so; raises PtamdError if it has not been built."""
     global _LIB
@@ -40,6 +69,7 @@ def lib():
     if not os.path.exists(path):
         raise PtamdError("%s is missing: build it with `make -C pathtracer_amd/csrc` "
                          "(there is no CPU fallback for the render path)" % path)
+    _share_torch_hip_runtime()
     L = C.CDLL(path)
     vp, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
     pd, pi = C.POINTER(C.c_double), C.POINTER(C.c_int32)

@@ -304,7 +304,11 @@ int ptamd_frame_resolve(ptamd_context *ctx, const double *d_state, double *d_hdr
  * distinct pixel indices in device memory. The work is queued on `stream`; the call returns
  * when the last round has been queued (it waits for earlier rounds' list lengths only).
  * This is what one rank of a multi-GPU render runs on its share of the pixels, and what
- * ptamd_render runs on the whole rectangle. */
+ * ptamd_render runs on the whole rectangle. Rounds too small to fill the GPU trace several
+ * batches per pixel ahead of the adaptive tests that decide whether they are needed (what lies
+ * past a pixel's stop is dropped: the frame is the one-batch-per-round frame, bit for bit);
+ * frames of 16 or more batches per pixel do so per pixel, as far as each pixel's running mean
+ * and variance predict it needs (ptamd_trace_list with sample_base = -1). */
 int ptamd_render_list(ptamd_context *ctx, const ptamd_render_params *params, const int32_t *d_pixels, int64_t n,
                       double *d_state, void *stream);
 /* Ordering: ptamd_render_list returns with its last rounds still queued and keeps, per context, the

@@ -61,7 +61,8 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--scene", default="dragon", help="dragon (stand-in), dragon-point (the stand-in with CBempty.dae's own point light: the earlier headline workload), "
                          "folded (the irregular stand-in), lucy (stand-in; configuration 4 of the benchmark table with --width 1920 "
-                         "--height 1080 --depth 8), bunny, spheres (configuration 5 with --depth 16), or a .dae path")
+                         "--height 1080 --depth 8), bunny, spheres (configuration 5 with --depth 16), cbsl (CBspheres_lambertian: configuration 1 "
+                         "with --width 480 --height 360 --light-samples 16), or a .dae path")
     ap.add_argument("--specular", action="store_true",
                     help="ideal mirror / glass instead of the reference's black stubs (the divergent-specular "
                          "stress: --scene spheres --specular --depth 16)")
@@ -121,6 +122,9 @@ def resolve_scene(name, rank):
                       "the reference checkout)"), 4096
     if name == "bunny":
         return os.path.join(ROOT, "scenes", "CBbunny.dae"), "CBbunny.dae", 256
+    if name == "cbsl":
+        # configuration 1 of the benchmark table with --width 480 --height 360 --light-samples 16
+        return os.path.join(ROOT, "scenes", "CBspheres_lambertian.dae"), "CBspheres_lambertian.dae", 64
     if name == "spheres":
         return os.path.join(ROOT, "scenes", "CBspheres.dae"), "CBspheres.dae", 1024
     return name, os.path.basename(name), 1024

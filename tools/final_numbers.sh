@@ -24,4 +24,4 @@ run folded --scene folded
 run lucy --scene lucy --width 1920 --height 1080 --depth 8
 run spheres --scene spheres --depth 16
 run spheres_spec --scene spheres --depth 16 --specular
-run cbsl --scene scenes/CBspheres_lambertian.dae --width 480 --height 360 --spp 64 --light-samples 16
+run cbsl --scene cbsl --width 480 --height 360 --light-samples 16

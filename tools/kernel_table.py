@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-kernel table of the committed counter summaries (profiles/r*_<workload>_summary.json, the latest of each
 workload): time per frame, HBM-side traffic, L2 hit rate, VALU busy, lanes on, lane-operations per second.
-usage: kernel_table.py [workload ...]   (default: dragon bunny lucy spheres folded)"""
+usage: kernel_table.py [workload ...]   (default: dragon bunny lucy spheres folded cbsl)"""
 import glob
 import json
 import os
@@ -17,7 +17,7 @@ ROWS = (("k_trace2<false, false>", "k_trace2ILb0ELb0"), ("k_shadow<false, false>
 
 
 def main():
-    for wl in (sys.argv[1:] or ["dragon", "bunny", "lucy", "spheres", "folded"]):
+    for wl in (sys.argv[1:] or ["dragon", "bunny", "lucy", "spheres", "folded", "cbsl"]):
         found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_summary.json" % wl)))
         if not found:
             continue

@@ -45,7 +45,10 @@ def test_render_frame_pipelined_equals_synchronous_equals_render(device):
                dict(lag=1, max_batches=4, target_paths=200000),
                # every pixel from its own count, traced ahead as far as its statistics predict
                dict(lag=1, per_pixel=True, sync_below=0), dict(lag=0, max_batches=2, per_pixel=True),
-               dict(lag=2, max_batches=6, target_paths=400000, per_pixel=True)):
+               dict(lag=2, max_batches=6, target_paths=400000, per_pixel=True),
+               # how fast the look-ahead may grow from round to round, and when the survivor count is read at once
+               dict(per_pixel=True, growth=1), dict(per_pixel=True, growth=0, sync_below=10 ** 9),
+               dict(per_pixel=True, growth=16, lag=2, target_paths=400000, sync_below=0)):
         rounds = []
         hdr, cnt = distributed.render_frame(device, p, device=cuda, record_rounds=rounds, **kw)
         assert np.array_equal(hdr.cpu().numpy(), hdr_b) and np.array_equal(cnt.cpu().numpy(), cnt_b), repr(kw)

@@ -1005,7 +1005,7 @@ int ptamd_render_list(ptamd_context *c, const ptamd_render_params *p, const int3
   const int batch = std::max(1, p->samples_per_batch);
   bool per_pixel = p->ns_aa >= 16 * batch;
   if (const char *e = getenv("PTAMD_PER_PIXEL")) per_pixel = atoi(e) != 0;
-  const int64_t sync_below = per_pixel ? 200000 : 0;
+  const int64_t sync_below = 200000;
   const int growth = 4;
   const int32_t *lists[2] = {d_pixels, nullptr};  // current list: the caller's, then the context's two in turn
   int32_t *own[2] = {f.d_list[0], f.d_list[1]};

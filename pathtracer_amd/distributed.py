@@ -151,8 +151,7 @@ def render_frame(dev, params, rank=0, world=1, group=None, device=None, record_r
     always agree in size. record_rounds, if a list, receives (samples_done,
     bound, this rank's share of the bound) per round.
 
-    sync_below: bounds at or below this many pixels are not lagged (see the loop). Default: 200000
-    with per_pixel (whose loop ends only when the list is seen to be empty), 0 otherwise.
+    sync_below: bounds at or below this many pixels are not lagged (see the loop). Default: 200000.
 
     growth (per_pixel only; default 4, 0: no limit): a round traces no pixel further ahead than this many
     times the samples the rounds before it traced ahead. A prediction made from one or two batches
@@ -217,7 +216,7 @@ def render_frame(dev, params, rank=0, world=1, group=None, device=None, record_r
     ahead = 0
     batch = params.samples_per_batch
     if sync_below is None:
-        sync_below = 200000 if per_pixel else 0
+        sync_below = 200000
     if growth is None:
         growth = 4
     # per_pixel: `done` is the least count any listed pixel can have (a pixel gains at

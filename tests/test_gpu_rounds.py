@@ -260,6 +260,51 @@ def test_one_call_frame_is_the_same_under_either_look_ahead_policy(device, monke
 
 
 @pytest.mark.skipif(_POLICY_OVERRIDDEN, reason="launch policy overridden in the environment")
+def test_headline_frame_is_the_same_under_every_launch_policy(monkeypatch):
+    """The benchmark's own frame (the 100k-triangle stand-in, 800x600, 1024 samples, depth 5, four light samples) at
+    full size, where rounds fill the buffers and long shadow-ray lists get launches of their own: bit-identical with
+    4 Mi and 1.5 Mi paths per launch instead of 16 Mi, with all pixels in lockstep, with k_light and k_resolve apart,
+    with bounce and shadow rays never or always in one launch, and with three times the look-ahead margin."""
+    import hashlib
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import make_standin_scene
+    make_standin_scene.ensure("dragon")
+    sc = pt.Scene(make_standin_scene.standin_path("dragon"))
+    p = cabi.make_params(800, 600, ns_aa=1024, max_ray_depth=5, ns_area_light=4, seed=42)
+
+    def frame(dev, max_paths=0):
+        dev.upload(sc)
+        dev.set_camera(sc.camera(800, 600))
+        dev.set_max_paths(max_paths)
+        hdr, cnt = dev.render(p)
+        dev.set_max_paths(0)
+        return hashlib.sha256(hdr.tobytes() + cnt.tobytes()).hexdigest(), int(cnt.sum())
+
+    for k in ("PTAMD_PER_PIXEL", "PTAMD_PLAN_MARGIN"):
+        monkeypatch.delenv(k, raising=False)
+    dev = pt.Device(0)
+    try:
+        want = frame(dev)
+        assert 0.15 * 800 * 600 * 1024 < want[1] < 0.5 * 800 * 600 * 1024
+        assert frame(dev, 4 << 20) == want
+        assert frame(dev, 3 << 19) == want
+        monkeypatch.setenv("PTAMD_PER_PIXEL", "0")
+        assert frame(dev) == want
+        monkeypatch.delenv("PTAMD_PER_PIXEL")
+    finally:
+        dev.close()
+    for k, v in (("PTAMD_FUSE_RESOLVE", "0"), ("PTAMD_TRACE_TWO", "0"), ("PTAMD_FUSE_BELOW", str(1 << 30)), ("PTAMD_PLAN_MARGIN", "3")):
+        monkeypatch.setenv(k, v)  # read when a context is created
+        other = pt.Device(0)
+        try:
+            assert frame(other) == want, k
+        finally:
+            other.close()
+            monkeypatch.delenv(k)
+
+
+@pytest.mark.skipif(_POLICY_OVERRIDDEN, reason="launch policy overridden in the environment")
 def test_event_classes_restrict_what_is_timed(device):
     p = _setup(device)
     device.set_profiling(events=True, counters=False)

@@ -440,6 +440,45 @@ def test_full_size_frame_properties(device):
     assert st.rays >= st.samples and st.shadow_rays < st.rays
 
 
+@pytest.mark.parametrize("tag,w,h,kw,rect", [
+    # configuration 3 (the headline) on its stand-in: a cell on the knot, where most pixels run to the full 1024 samples
+    ("dragon", 800, 600, dict(ns_aa=1024, max_ray_depth=5, ns_area_light=4), (388, 290, 412, 318)),
+    # configuration 2
+    ("CBbunny", 800, 600, dict(ns_aa=256, max_ray_depth=5, ns_area_light=4), (380, 200, 420, 240)),
+    # configuration 4 on its stand-in
+    ("lucy", 1920, 1080, dict(ns_aa=4096, max_ray_depth=8, ns_area_light=4), (954, 536, 966, 546)),
+    # configurations 5 (black stub spheres) and 1
+    ("CBspheres", 800, 600, dict(ns_aa=1024, max_ray_depth=16, ns_area_light=4), (380, 200, 420, 240)),
+    ("CBspheres_lambertian", 480, 360, dict(ns_aa=64, max_ray_depth=5, ns_area_light=16), (200, 120, 280, 200)),
+])
+def test_cells_of_the_full_size_benchmark_frames_match_the_oracle(device, tag, w, h, kw, rect):
+    """The benchmark table's frames at FULL size and full sample budgets, rendered whole by the HIP path (rounds that
+    fill the buffers, long shadow-ray lists, per-pixel look-ahead), against the oracle on a cell of the same frame:
+    samples are keyed by pixel and index, so the cell's pixels must agree to rounding like the small frames of
+    test_render_matches_oracle do."""
+    import os
+    import sys
+    if tag.startswith("CB"):
+        path = scene_path(tag)
+    else:
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+        import make_standin_scene
+        make_standin_scene.ensure(tag)
+        path = make_standin_scene.standin_path(tag)
+    sc = pt.Scene(path)
+    arr, cam = sc.arrays(), sc.camera(w, h)
+    device.upload(sc)
+    device.set_camera(cam)
+    hdr, cnt = device.render(cabi.make_params(w, h, seed=77, **kw))
+    x0, y0, x1, y1 = rect
+    rh, rc, _ = O.render(arr, cam, cabi.make_params(w, h, seed=77, rect=rect, **kw), threads=8)
+    g, gc, r, rcn = hdr[y0:y1, x0:x1], cnt[y0:y1, x0:x1], rh[y0:y1, x0:x1], rc[y0:y1, x0:x1]
+    assert rcn.sum() > 0 and gc.max() >= min(kw["ns_aa"], 256), "the cell must hold pixels that run for many batches"
+    assert (gc == rcn).mean() >= 0.995, "sample counts differ on %d of %d pixels" % ((gc != rcn).sum(), gc.size)
+    close = np.isclose(g, r, rtol=1e-9, atol=1e-12).all(axis=2)
+    assert close.mean() >= 0.995, "%d of %d pixels differ beyond rounding" % ((~close).sum(), close.size)
+
+
 def test_deep_bvh_spills_the_lane_stack(device):
     """The 100k-triangle stand-in scene has a tree deeper than the LDS part of the per-lane
     stack; results must not depend on where a stack level lives."""

@@ -283,6 +283,8 @@ int main(int argc, char **argv) {
     size_t children = 0, prim_children = 0;
     for (auto &n : T.nodes) { children += n.child.size(); for (int c : n.child) prim_children += c < 0; }
     Counts cam_c, bounce_c, shadow_c;
+    // shadow rays that the occluder of the shadow ray before them (in generation order) also occludes
+    double sc_rays = 0, sc_occluded = 0, sc_cache_hit = 0, sc_trips_all = 0, sc_trips_hit = 0; int last_occ = -1;
     std::mt19937_64 rng(7);
     std::uniform_real_distribution<double> U(0, 1);
     const double th = std::tan(cam.hFov * M_PI / 360), tv = std::tan(cam.vFov * M_PI / 360);
@@ -319,7 +321,16 @@ int main(int argc, char **argv) {
               const V3 S{L[3] + L[9] * ax + L[12] * ay, L[4] + L[10] * ax + L[13] * ay, L[5] + L[11] * ax + L[14] * ay};
               const V3 dd = S - hp; const double dist = std::sqrt(dot(dd, dd));
               if (dot(dd, n) <= 0) continue;
-              trace(d, T, hp, dd * (1 / dist), 1e-11, dist * (1 - 1e-6), true, shadow_c, p, leaves);
+              Counts one;
+              const V3 sd = dd * (1 / dist);
+              const int occ = trace(d, T, hp, sd, 1e-11, dist * (1 - 1e-6), true, one, p, leaves);
+              shadow_c.rays += one.rays; shadow_c.visits += one.visits; shadow_c.boxes += one.boxes; shadow_c.tests += one.tests;
+              shadow_c.trips += one.trips; shadow_c.leaf_steps += one.leaf_steps;
+              sc_rays++; sc_trips_all += one.trips;
+              if (occ >= 0) sc_occluded++;
+              double tc;
+              if (last_occ >= 0 && last_occ != p && prim_hit(d, last_occ, hp, sd, 1e-11, dist * (1 - 1e-6), tc)) { sc_cache_hit++; sc_trips_hit += one.trips; }
+              if (occ >= 0) last_occ = occ;
             }
           }
           // cosine-weighted bounce
@@ -339,6 +350,9 @@ int main(int argc, char **argv) {
     printf(" W=%d%s%s: %zu nodes, %.2f children per node (%.2f of them %s)\n", W, leaves ? " with whole leaves" : "", optimal ? " collapsed for the least summed node area" : "", T.nodes.size(),
            (double)children / T.nodes.size(), (double)prim_children / T.nodes.size(), leaves ? "leaves" : "primitives");
     pr("camera", cam_c); pr("bounce", bounce_c); pr("shadow", shadow_c);
+    if (mode == 1)
+      printf("  W= 4 shadow rays occluded: %.1f %%; occluded by the occluder of the shadow ray before them: %.1f %% of all, holding %.1f %% of the shadow rays' trips\n",
+             100 * sc_occluded / sc_rays, 100 * sc_cache_hit / sc_rays, 100 * sc_trips_hit / sc_trips_all);
   }
   ptamd_scene_free(sc);
   return 0;
